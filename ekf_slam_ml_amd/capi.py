@@ -1,0 +1,327 @@
+"""ctypes binding of libekfslam_hip.so (include/ekfslam.h) -- the only way Python reaches the filter.
+
+There is no fallback: if the shared library is missing or no gfx950 device is visible, every
+constructor raises.  The classes mirror the reference's call surface:
+
+  EKF_SLAM      rigid2d::EKF_SLAM                      rigid2d/include/rigid2d/ekf_slam.hpp:19-57
+  BatchEKF      B independent EKF_SLAM objects driven by a device-resident log (configs[4])
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libekfslam_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_bp = C.POINTER(C.c_uint8)
+
+STATUS = {0: "EKF_OK", 1: "EKF_ERR_INVALID", 2: "EKF_ERR_NO_DEVICE", 3: "EKF_ERR_HIP", 4: "EKF_ERR_NOMEM",
+          5: "EKF_ERR_STATE"}
+
+# every symbol include/ekfslam.h declares (tests/test_capi_symbols.py checks the .so exports them all)
+SYMBOLS = [
+    "ekf_last_error", "ekf_default_params", "ekf_device_count",
+    "ekf_create", "ekf_destroy", "ekf_clone", "ekf_predict", "ekf_measure_known", "ekf_associate",
+    "ekf_maha_scores", "ekf_get_pose", "ekf_get_landmarks", "ekf_dim", "ekf_get_state", "ekf_set_state",
+    "ekf_get_cov", "ekf_set_cov", "ekf_get_init_flag", "ekf_set_init_flag", "ekf_sync", "ekf_set_tuning",
+    "ekf_batch_create", "ekf_batch_destroy", "ekf_batch_reset", "ekf_batch_device_bytes",
+    "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_get_state", "ekf_batch_get_cov",
+    "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
+]
+
+
+class EkfError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"{STATUS.get(status, status)}: {text}")
+        self.status = status
+
+
+class Params(C.Structure):
+    """ekf_params (include/ekfslam.h); defaults are the reference's hard-coded constants."""
+    _fields_ = [("sigma0_landmark", C.c_double), ("q_pose", C.c_double), ("r_meas", C.c_double),
+                ("gate_new", C.c_double), ("gate_update", C.c_double), ("straight_eps", C.c_double)]
+
+
+class KnownLogC(C.Structure):
+    _fields_ = [("T", C.c_int), ("vmax", C.c_int), ("twist", _dp), ("lm_idx", _ip), ("z_xy", _dp), ("init_xy", _dp)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("elapsed_ms", C.c_double), ("rank2_ms", C.c_double), ("rank2_launches", C.c_longlong),
+                ("corrections", C.c_longlong), ("filter_steps", C.c_longlong),
+                ("rank2_bytes_per_launch", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    """Load libekfslam_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch bundles its own libamdhip64.so.7; if torch will be used in this process it must be loaded
+    # first so that both share ONE HIP runtime (the dynamic loader dedups by SONAME).
+    lib = C.CDLL(LIB_PATH)
+    h = C.c_void_p
+    lib.ekf_last_error.restype = C.c_char_p
+    lib.ekf_default_params.argtypes = [C.POINTER(Params)]
+    lib.ekf_device_count.restype = C.c_int
+    sig = {
+        "ekf_create": [C.c_int, C.POINTER(Params), C.c_int, C.POINTER(h)],
+        "ekf_destroy": [h],
+        "ekf_clone": [h, C.POINTER(h)],
+        "ekf_predict": [h, C.c_double, C.c_double],
+        "ekf_measure_known": [h, _dp, _bp],
+        "ekf_associate": [h, _dp, C.c_int, _bp, _ip],
+        "ekf_maha_scores": [h, C.c_double, C.c_double, C.c_int, _dp],
+        "ekf_get_pose": [h, _dp],
+        "ekf_get_landmarks": [h, _dp],
+        "ekf_dim": [h, _ip, _ip],
+        "ekf_get_state": [h, _dp],
+        "ekf_set_state": [h, _dp],
+        "ekf_get_cov": [h, _dp],
+        "ekf_set_cov": [h, _dp],
+        "ekf_get_init_flag": [h, _ip],
+        "ekf_set_init_flag": [h, C.c_int],
+        "ekf_sync": [h],
+        "ekf_set_tuning": [h, C.c_int, C.c_int],
+        "ekf_batch_create": [C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.POINTER(h)],
+        "ekf_batch_destroy": [h],
+        "ekf_batch_reset": [h],
+        "ekf_batch_device_bytes": [h, C.POINTER(C.c_size_t)],
+        "ekf_batch_upload_known_log": [h, C.POINTER(KnownLogC)],
+        "ekf_batch_run_known": [h, C.c_int, C.c_int, C.c_int, C.POINTER(RunStats)],
+        "ekf_batch_get_state": [h, C.c_int, _dp],
+        "ekf_batch_get_cov": [h, C.c_int, _dp],
+        "ekf_batch_get_poses": [h, _dp],
+        "ekf_batch_checksum": [h, _dp],
+        "ekf_batch_set_tuning": [h, C.c_int, C.c_int],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(st):
+    if st != 0:
+        raise EkfError(st, load().ekf_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return load().ekf_device_count()
+
+
+def default_params():
+    p = Params()
+    load().ekf_default_params(C.byref(p))
+    return p
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+class EKF_SLAM:
+    """rigid2d::EKF_SLAM over the C ABI: same method names, argument meaning and in/out behaviour
+    as rigid2d/include/rigid2d/ekf_slam.hpp:19-57 (arma::mat -> float64 array,
+    std::vector<bool> -> uint8 array, Twist2D -> (angular, linearX), Vector2D -> (x, y) rows)."""
+
+    def __init__(self, n_measurements, params=None, device=-1, _handle=None):
+        self._lib = load()
+        self.n = int(n_measurements)
+        self.N = 3 + 2 * self.n
+        if _handle is not None:
+            self._h = _handle
+            return
+        h = C.c_void_p()
+        _check(self._lib.ekf_create(self.n, C.byref(params) if params is not None else None, device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ekf_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def clone(self):
+        """Copy construction / assignment (slam_agent = EKF_SLAM(n), nuslam/src/slam.cpp:428)."""
+        h = C.c_void_p()
+        _check(self._lib.ekf_clone(self._h, C.byref(h)))
+        return EKF_SLAM(self.n, _handle=h)
+
+    def prediction(self, twist):
+        """twist = (angular, linearX[, linearY]); linearY is ignored like ekf_slam.cpp:70."""
+        _check(self._lib.ekf_predict(self._h, float(twist[0]), float(twist[1])))
+
+    def measurement(self, sensor_reading, visible_list, known_list=None):
+        s = np.ascontiguousarray(sensor_reading, dtype=np.float64).reshape(-1)
+        v = np.ascontiguousarray(visible_list, dtype=np.uint8).reshape(-1)
+        if s.size != 2 * self.n or v.size != self.n:
+            raise ValueError("sensor_reading must hold 2n values and visible_list n")
+        _check(self._lib.ekf_measure_known(self._h, _d(s), v.ctypes.data_as(_bp)))
+
+    def data_association(self, measures, known_list):
+        """known_list: uint8 ndarray of n entries, updated IN PLACE (ekf_slam.cpp:323).
+        Returns the landmark each measurement corrected (-1 = dropped)."""
+        m = np.ascontiguousarray(measures, dtype=np.float64).reshape(-1, 2)
+        if not (isinstance(known_list, np.ndarray) and known_list.dtype == np.uint8
+                and known_list.size == self.n and known_list.flags.c_contiguous):
+            raise ValueError("known_list must be a contiguous uint8 array of n entries (it is in/out)")
+        assoc = np.full(len(m), -1, dtype=np.int32)
+        _check(self._lib.ekf_associate(self._h, _d(m), len(m), known_list.ctypes.data_as(_bp),
+                                       assoc.ctypes.data_as(_ip)))
+        return assoc
+
+    def maha_scores(self, measure, M):
+        out = np.empty(int(M))
+        _check(self._lib.ekf_maha_scores(self._h, float(measure[0]), float(measure[1]), int(M), _d(out)))
+        return out
+
+    def _pose(self):
+        out = np.empty(3)
+        _check(self._lib.ekf_get_pose(self._h, _d(out)))
+        return out
+
+    def getStateX(self):
+        return float(self._pose()[1])
+
+    def getStateY(self):
+        return float(self._pose()[2])
+
+    def getStateTheta(self):
+        return float(self._pose()[0])
+
+    def getStateLandmark(self):
+        out = np.empty(2 * self.n)
+        _check(self._lib.ekf_get_landmarks(self._h, _d(out)))
+        return out
+
+    @property
+    def state(self):
+        out = np.empty(self.N)
+        _check(self._lib.ekf_get_state(self._h, _d(out)))
+        return out
+
+    @state.setter
+    def state(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1)
+        if v.size != self.N:
+            raise ValueError("state must hold N = 3 + 2n values")
+        _check(self._lib.ekf_set_state(self._h, _d(v)))
+
+    @property
+    def cov(self):
+        out = np.empty((self.N, self.N))
+        _check(self._lib.ekf_get_cov(self._h, _d(out)))
+        return out
+
+    @cov.setter
+    def cov(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        if v.shape != (self.N, self.N):
+            raise ValueError("cov must be N x N")
+        _check(self._lib.ekf_set_cov(self._h, _d(v)))
+
+    @property
+    def landmark_init_flag(self):
+        f = C.c_int()
+        _check(self._lib.ekf_get_init_flag(self._h, C.byref(f)))
+        return bool(f.value)
+
+    @landmark_init_flag.setter
+    def landmark_init_flag(self, f):
+        _check(self._lib.ekf_set_init_flag(self._h, int(bool(f))))
+
+    def sync(self):
+        _check(self._lib.ekf_sync(self._h))
+
+    def set_tuning(self, rows_per_block=0, nontemporal=-1):
+        _check(self._lib.ekf_set_tuning(self._h, rows_per_block, nontemporal))
+
+
+class BatchEKF:
+    """B independent filters on one GPU, replaying a device-resident known-association log."""
+
+    def __init__(self, B, n, params=None, device=-1):
+        self._lib = load()
+        self.B, self.n, self.N = int(B), int(n), 3 + 2 * int(n)
+        h = C.c_void_p()
+        _check(self._lib.ekf_batch_create(self.B, self.n, C.byref(params) if params is not None else None,
+                                          device, C.byref(h)))
+        self._h = h
+        self.T = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ekf_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        _check(self._lib.ekf_batch_reset(self._h))
+
+    def device_bytes(self):
+        b = C.c_size_t()
+        _check(self._lib.ekf_batch_device_bytes(self._h, C.byref(b)))
+        return b.value
+
+    def upload_known_log(self, twist, lm_idx, z_xy, init_xy):
+        tw = np.ascontiguousarray(twist, dtype=np.float64)
+        li = np.ascontiguousarray(lm_idx, dtype=np.int32)
+        zz = np.ascontiguousarray(z_xy, dtype=np.float64)
+        ii = np.ascontiguousarray(init_xy, dtype=np.float64)
+        T, B = tw.shape[0], tw.shape[1]
+        if B != self.B or tw.shape != (T, B, 2) or li.shape[:2] != (T, B) or zz.shape != li.shape + (2,) \
+                or ii.shape != (B, 2 * self.n):
+            raise ValueError("log arrays must be twist[T,B,2], lm_idx[T,B,vmax], z_xy[T,B,vmax,2], init_xy[B,2n]")
+        log = KnownLogC(T, li.shape[2], _d(tw), li.ctypes.data_as(_ip), _d(zz), _d(ii))
+        _check(self._lib.ekf_batch_upload_known_log(self._h, C.byref(log)))
+        self.T = T
+
+    def run_known(self, t_begin=0, t_end=None, time_kernels=False):
+        st = RunStats()
+        _check(self._lib.ekf_batch_run_known(self._h, t_begin, self.T if t_end is None else t_end,
+                                             int(time_kernels), C.byref(st)))
+        return st.as_dict()
+
+    def state(self, b):
+        out = np.empty(self.N)
+        _check(self._lib.ekf_batch_get_state(self._h, int(b), _d(out)))
+        return out
+
+    def cov(self, b):
+        out = np.empty((self.N, self.N))
+        _check(self._lib.ekf_batch_get_cov(self._h, int(b), _d(out)))
+        return out
+
+    def poses(self):
+        out = np.empty((self.B, 3))
+        _check(self._lib.ekf_batch_get_poses(self._h, _d(out)))
+        return out
+
+    def checksum(self):
+        out = np.empty(4)
+        _check(self._lib.ekf_batch_checksum(self._h, _d(out)))
+        return out
+
+    def set_tuning(self, rows_per_block=0, nontemporal=-1):
+        _check(self._lib.ekf_batch_set_tuning(self._h, rows_per_block, nontemporal))

@@ -1,0 +1,643 @@
+// ekf_capi.hip -- the C ABI of include/ekfslam.h over the gfx950 kernels (ekf_kernels.hip).
+// Host runtime of the filter core: device pools, pinned staging, stream ordering, event timing.
+// No CPU fallback exists: without a gfx950 device every entry point fails with EKF_ERR_NO_DEVICE.
+#include "../../include/ekfslam.h"
+#include "ekf_kernels.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+ekf_status fail(ekf_status st, const std::string& msg) {
+    g_err = msg;
+    return st;
+}
+
+#define HIPC(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(e_ == hipErrorOutOfMemory ? EKF_ERR_NOMEM : EKF_ERR_HIP,                \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+#define EKFC(expr)                        \
+    do {                                  \
+        ekf_status s_ = (expr);           \
+        if (s_ != EKF_OK) return s_;      \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// pinned host buffer whose last async use is guarded by an event
+struct Staging {
+    void* host = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+
+    ekf_status reserve(size_t need) {
+        if (need <= bytes) return EKF_OK;
+        EKFC(wait());
+        if (host) HIPC(hipHostFree(host));
+        host = nullptr; bytes = 0;
+        HIPC(hipHostMalloc(&host, need, hipHostMallocDefault));
+        bytes = need;
+        if (!ev) HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        return EKF_OK;
+    }
+    ekf_status wait() {
+        if (pending) { HIPC(hipEventSynchronize(ev)); pending = false; }
+        return EKF_OK;
+    }
+    ekf_status mark(hipStream_t s) {
+        HIPC(hipEventRecord(ev, s));
+        pending = true;
+        return EKF_OK;
+    }
+    void release() {
+        if (host) (void)hipHostFree(host);
+        if (ev) (void)hipEventDestroy(ev);
+        host = nullptr; ev = nullptr; bytes = 0; pending = false;
+    }
+};
+
+struct Pool {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    ekf::PoolView pv{};
+    ekf::Rank2Tuning tuning{0, -1};
+    size_t dev_bytes = 0;
+    int init_flag = 0;  // landmark_init_flag, ekf_slam.hpp:65
+
+    // association / single-filter staging (device)
+    double* scores = nullptr;    // [B][n]
+    double* meas_dev = nullptr;  // [jcap][2]
+    int* assoc_out_dev = nullptr;  // [jcap]
+    int jcap = 0;
+    double* sensor_dev = nullptr;  // [2n] (single filter)
+    double* digest_dev = nullptr;  // [B][4]
+    double* poses_dev = nullptr;   // [B][3]
+    Staging stage_in, stage_out;
+
+    // uploaded known-association log (device) + per-(step, slot) active-filter counts (host)
+    int T = 0, vmax = 0;
+    double* log_twist = nullptr;
+    int* log_lm = nullptr;
+    double* log_z = nullptr;
+    double* log_init = nullptr;
+    size_t log_bytes = 0;
+    std::vector<int> slot_active;  // [T][vmax]
+
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+    ekf_status use() {
+        HIPC(hipSetDevice(device));
+        return EKF_OK;
+    }
+
+    template <class Tp>
+    ekf_status dalloc(Tp** p, size_t count) {
+        HIPC(hipMalloc((void**)p, count * sizeof(Tp)));
+        dev_bytes += count * sizeof(Tp);
+        return EKF_OK;
+    }
+
+    ekf_status create(int B, int n, const ekf_params* params, int dev) {
+        if (B <= 0 || n < 0) return fail(EKF_ERR_INVALID, "B must be > 0 and n >= 0");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return fail(EKF_ERR_NO_DEVICE, "no HIP device visible: libekfslam_hip has no CPU path");
+        if (dev < 0) HIPC(hipGetDevice(&dev));
+        if (dev >= count) return fail(EKF_ERR_INVALID, "device index out of range");
+        hipDeviceProp_t prop;
+        HIPC(hipGetDeviceProperties(&prop, dev));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(EKF_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+        device = dev;
+        EKFC(use());
+        HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        ekf_params p;
+        ekf_default_params(&p);
+        if (params) p = *params;
+        pv.p = ekf::Params{p.sigma0_landmark, p.q_pose, p.r_meas, p.gate_new, p.gate_update, p.straight_eps};
+        pv.n = n;
+        pv.N = 3 + 2 * n;
+        pv.ld = round_up(pv.N, 16);
+        pv.B = B;
+        pv.sigma_stride = (size_t)pv.N * pv.ld;
+        EKFC(dalloc(&pv.sigma, (size_t)B * pv.sigma_stride));
+        EKFC(dalloc(&pv.state, (size_t)B * pv.ld));
+        EKFC(dalloc(&pv.Kg, (size_t)B * 2 * pv.ld));
+        EKFC(dalloc(&pv.Gh, (size_t)B * 2 * pv.ld));
+        EKFC(dalloc(&pv.snap, (size_t)B * 4));
+        EKFC(dalloc(&pv.rec, (size_t)B));
+        EKFC(dalloc(&pv.assoc, (size_t)B));
+        EKFC(dalloc(&scores, (size_t)B * (n > 0 ? n : 1)));
+        EKFC(dalloc(&digest_dev, (size_t)B * 4));
+        EKFC(dalloc(&poses_dev, (size_t)B * 3));
+        HIPC(hipEventCreate(&ev_begin));
+        HIPC(hipEventCreate(&ev_end));
+        return reset();
+    }
+
+    ekf_status reset() {
+        EKFC(use());
+        ekf::launch_init(pv, stream);
+        HIPC(hipGetLastError());
+        init_flag = 0;
+        return EKF_OK;
+    }
+
+    void destroy() {
+        if (device >= 0) (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, scores, meas_dev,
+                        assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        stage_in.release();
+        stage_out.release();
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_end) (void)hipEventDestroy(ev_end);
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+
+    ekf_status sync() {
+        EKFC(use());
+        HIPC(hipStreamSynchronize(stream));
+        return EKF_OK;
+    }
+
+    // host -> device through the pinned staging buffer, ordered on the stream
+    ekf_status upload(void* dst, const void* src, size_t bytes) {
+        if (bytes == 0) return EKF_OK;
+        EKFC(stage_in.reserve(bytes));
+        EKFC(stage_in.wait());
+        std::memcpy(stage_in.host, src, bytes);
+        HIPC(hipMemcpyAsync(dst, stage_in.host, bytes, hipMemcpyHostToDevice, stream));
+        return stage_in.mark(stream);
+    }
+
+    // device -> host, blocking
+    ekf_status download(void* dst, const void* src, size_t bytes) {
+        if (bytes == 0) return EKF_OK;
+        EKFC(stage_out.reserve(bytes));
+        HIPC(hipMemcpyAsync(stage_out.host, src, bytes, hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        std::memcpy(dst, stage_out.host, bytes);
+        return EKF_OK;
+    }
+
+    ekf_status get_state(int b, double* out) {
+        if (!out || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "get_state: bad argument");
+        EKFC(use());
+        return download(out, pv.state + (size_t)b * pv.ld, sizeof(double) * pv.N);
+    }
+
+    ekf_status set_state(int b, const double* in) {
+        if (!in || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "set_state: bad argument");
+        EKFC(use());
+        return upload(pv.state + (size_t)b * pv.ld, in, sizeof(double) * pv.N);
+    }
+
+    ekf_status get_cov(int b, double* out) {
+        if (!out || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "get_cov: bad argument");
+        EKFC(use());
+        const size_t w = sizeof(double) * pv.N;
+        EKFC(stage_out.reserve(w * pv.N));
+        HIPC(hipMemcpy2DAsync(stage_out.host, w, pv.sigma + (size_t)b * pv.sigma_stride, sizeof(double) * pv.ld, w,
+                              pv.N, hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        std::memcpy(out, stage_out.host, w * pv.N);
+        return EKF_OK;
+    }
+
+    ekf_status set_cov(int b, const double* in) {
+        if (!in || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "set_cov: bad argument");
+        EKFC(use());
+        const size_t w = sizeof(double) * pv.N;
+        EKFC(stage_in.reserve(w * pv.N));
+        EKFC(stage_in.wait());
+        std::memcpy(stage_in.host, in, w * pv.N);
+        HIPC(hipMemcpy2DAsync(pv.sigma + (size_t)b * pv.sigma_stride, sizeof(double) * pv.ld, stage_in.host, w, w,
+                              pv.N, hipMemcpyHostToDevice, stream));
+        return stage_in.mark(stream);
+    }
+
+    ekf_status ensure_meas_capacity(int J) {
+        if (J <= jcap) return EKF_OK;
+        HIPC(hipStreamSynchronize(stream));
+        if (meas_dev) HIPC(hipFree(meas_dev));
+        if (assoc_out_dev) HIPC(hipFree(assoc_out_dev));
+        meas_dev = nullptr; assoc_out_dev = nullptr;
+        const int cap = J < 64 ? 64 : round_up(J, 64);
+        EKFC(dalloc(&meas_dev, (size_t)cap * 2));
+        EKFC(dalloc(&assoc_out_dev, (size_t)cap));
+        jcap = cap;
+        return EKF_OK;
+    }
+
+    hipEvent_t* events(size_t need) {
+        while (ev_pool.size() < need) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ev_pool.push_back(e);
+        }
+        return ev_pool.data();
+    }
+};
+
+ekf_status checked_launch() {
+    HIPC(hipGetLastError());
+    return EKF_OK;
+}
+
+}  // namespace
+
+struct ekf_filter_s { Pool pool; };
+struct ekf_batch_s { Pool pool; };
+
+extern "C" {
+
+const char* ekf_last_error(void) { return g_err.c_str(); }
+
+void ekf_default_params(ekf_params* out) {
+    if (!out) return;
+    out->sigma0_landmark = 100.0;  // ekf_slam.cpp:32
+    out->q_pose = 0.0001;          // ekf_slam.cpp:41-43
+    out->r_meas = 0.01;            // ekf_slam.cpp:174-175
+    out->gate_new = 10.0;          // ekf_slam.cpp:293
+    out->gate_update = 1.0;        // ekf_slam.cpp:330
+    out->straight_eps = 0.000001;  // ekf_slam.cpp:79
+}
+
+int ekf_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+// ---- single filter -------------------------------------------------------------------------
+
+ekf_status ekf_create(int n, const ekf_params* params, int device, ekf_handle* out) {
+    if (!out) return fail(EKF_ERR_INVALID, "ekf_create: out is null");
+    *out = nullptr;
+    ekf_filter_s* f = new (std::nothrow) ekf_filter_s();
+    if (!f) return fail(EKF_ERR_NOMEM, "host allocation failed");
+    ekf_status st = f->pool.create(1, n, params, device);
+    if (st == EKF_OK) st = f->pool.dalloc(&f->pool.sensor_dev, (size_t)(n > 0 ? 2 * n : 2));
+    if (st != EKF_OK) {
+        f->pool.destroy();
+        delete f;
+        return st;
+    }
+    *out = f;
+    return EKF_OK;
+}
+
+ekf_status ekf_destroy(ekf_handle h) {
+    if (!h) return EKF_OK;
+    h->pool.destroy();
+    delete h;
+    return EKF_OK;
+}
+
+ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
+    if (!h || !out) return fail(EKF_ERR_INVALID, "ekf_clone: null argument");
+    Pool& a = h->pool;
+    ekf_params p{a.pv.p.sigma0_landmark, a.pv.p.q_pose, a.pv.p.r_meas, a.pv.p.gate_new, a.pv.p.gate_update,
+                 a.pv.p.straight_eps};
+    EKFC(ekf_create(a.pv.n, &p, a.device, out));
+    Pool& c = (*out)->pool;
+    EKFC(a.sync());
+    HIPC(hipMemcpyAsync(c.pv.sigma, a.pv.sigma, sizeof(double) * a.pv.sigma_stride, hipMemcpyDeviceToDevice, c.stream));
+    HIPC(hipMemcpyAsync(c.pv.state, a.pv.state, sizeof(double) * a.pv.ld, hipMemcpyDeviceToDevice, c.stream));
+    c.init_flag = a.init_flag;
+    c.tuning = a.tuning;
+    return c.sync();
+}
+
+ekf_status ekf_predict(ekf_handle h, double dtheta, double dx) {
+    if (!h) return fail(EKF_ERR_INVALID, "ekf_predict: null handle");
+    Pool& P = h->pool;
+    EKFC(P.use());
+    ekf::launch_predict(P.pv, nullptr, dtheta, dx, P.stream);
+    return checked_launch();
+}
+
+ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_t* visible) {
+    if (!h || !sensor_xy || !visible) return fail(EKF_ERR_INVALID, "ekf_measure_known: null argument");
+    Pool& P = h->pool;
+    EKFC(P.use());
+    const int n = P.pv.n;
+    EKFC(P.upload(P.sensor_dev, sensor_xy, sizeof(double) * 2 * n));
+    ekf::launch_measure_begin(P.pv, P.sensor_dev, !P.init_flag, P.stream);  // ekf_slam.cpp:109-128
+    P.init_flag = 1;
+    ekf::CmdSrc src{};
+    src.mode = ekf::SRC_SENSOR_VECTOR;
+    src.sensor = P.sensor_dev;
+    src.fresh_pose = 0;
+    for (int i = 0; i < n; i++) {  // ekf_slam.cpp:132-194, ascending landmark order
+        if (!visible[i]) continue;
+        src.lm_imm = i;
+        ekf::launch_gain(P.pv, src, P.stream);
+        ekf::launch_rank2(P.pv, P.tuning, P.stream);
+    }
+    return checked_launch();
+}
+
+ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* known, int* assoc_out) {
+    if (!h || !known || J < 0 || (J > 0 && !meas_xy)) return fail(EKF_ERR_INVALID, "ekf_associate: bad argument");
+    Pool& P = h->pool;
+    EKFC(P.use());
+    const int n = P.pv.n;
+    int known_count = 0;  // ekf_slam.cpp:281-288: leading run of true
+    for (int i = 0; i < n; i++) {
+        if (known[i]) known_count++; else break;
+    }
+    if (J == 0) return EKF_OK;
+    EKFC(P.ensure_meas_capacity(J));
+    EKFC(P.upload(P.meas_dev, meas_xy, sizeof(double) * 2 * J));
+    ekf::launch_assoc_begin(P.pv, nullptr, known_count, P.stream);
+    ekf::CmdSrc src{};
+    src.mode = ekf::SRC_ASSOC;
+    src.assoc = P.pv.assoc;
+    src.fresh_pose = 1;
+    for (int j = 0; j < J; j++) {  // ekf_slam.cpp:291: sequential, state-carrying
+        const double* mj = P.meas_dev + 2 * (size_t)j;
+        ekf::launch_maha(P.pv, mj, P.scores, -1, P.stream);                               // :300-309
+        ekf::launch_assoc_decide(P.pv, mj, P.scores, P.assoc_out_dev, 0, j, P.stream);    // :293-330
+        src.meas = mj;
+        ekf::launch_gain(P.pv, src, P.stream);                                            // :331-385
+        ekf::launch_rank2(P.pv, P.tuning, P.stream);                                      // :389-390
+    }
+    EKFC(checked_launch());
+    ekf::AssocRec rec;
+    EKFC(P.download(&rec, P.pv.assoc, sizeof(rec)));
+    for (int i = known_count; i < rec.known_count && i < n; i++) known[i] = 1;  // :323
+    if (assoc_out) EKFC(P.download(assoc_out, P.assoc_out_dev, sizeof(int) * J));
+    return EKF_OK;
+}
+
+ekf_status ekf_maha_scores(ekf_handle h, double meas_x, double meas_y, int M, double* scores_out) {
+    if (!h || !scores_out || M < 0) return fail(EKF_ERR_INVALID, "ekf_maha_scores: bad argument");
+    Pool& P = h->pool;
+    if (M > P.pv.n) return fail(EKF_ERR_INVALID, "ekf_maha_scores: M exceeds the number of landmarks");
+    if (M == 0) return EKF_OK;
+    EKFC(P.use());
+    EKFC(P.ensure_meas_capacity(1));
+    const double m[2] = {meas_x, meas_y};
+    EKFC(P.upload(P.meas_dev, m, sizeof(m)));
+    ekf::launch_maha(P.pv, P.meas_dev, P.scores, M, P.stream);
+    EKFC(checked_launch());
+    return P.download(scores_out, P.scores, sizeof(double) * M);
+}
+
+ekf_status ekf_get_pose(ekf_handle h, double out[3]) {
+    if (!h || !out) return fail(EKF_ERR_INVALID, "ekf_get_pose: null argument");
+    EKFC(h->pool.use());
+    return h->pool.download(out, h->pool.pv.state, sizeof(double) * 3);
+}
+
+ekf_status ekf_get_landmarks(ekf_handle h, double* out) {
+    if (!h || !out) return fail(EKF_ERR_INVALID, "ekf_get_landmarks: null argument");
+    EKFC(h->pool.use());
+    return h->pool.download(out, h->pool.pv.state + 3, sizeof(double) * 2 * h->pool.pv.n);
+}
+
+ekf_status ekf_dim(ekf_handle h, int* n, int* N) {
+    if (!h) return fail(EKF_ERR_INVALID, "ekf_dim: null handle");
+    if (n) *n = h->pool.pv.n;
+    if (N) *N = h->pool.pv.N;
+    return EKF_OK;
+}
+
+ekf_status ekf_get_state(ekf_handle h, double* out) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    return h->pool.get_state(0, out);
+}
+ekf_status ekf_set_state(ekf_handle h, const double* in) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    return h->pool.set_state(0, in);
+}
+ekf_status ekf_get_cov(ekf_handle h, double* out) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    return h->pool.get_cov(0, out);
+}
+ekf_status ekf_set_cov(ekf_handle h, const double* in) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    return h->pool.set_cov(0, in);
+}
+ekf_status ekf_get_init_flag(ekf_handle h, int* flag) {
+    if (!h || !flag) return fail(EKF_ERR_INVALID, "null argument");
+    *flag = h->pool.init_flag;
+    return EKF_OK;
+}
+ekf_status ekf_set_init_flag(ekf_handle h, int flag) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    h->pool.init_flag = flag ? 1 : 0;
+    return EKF_OK;
+}
+ekf_status ekf_sync(ekf_handle h) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    return h->pool.sync();
+}
+ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    h->pool.tuning = ekf::Rank2Tuning{rows_per_block, nontemporal};
+    return EKF_OK;
+}
+
+// ---- batch ---------------------------------------------------------------------------------
+
+ekf_status ekf_batch_create(int B, int n, const ekf_params* params, int device, ekf_batch_handle* out) {
+    if (!out) return fail(EKF_ERR_INVALID, "ekf_batch_create: out is null");
+    *out = nullptr;
+    if (B > 65535) return fail(EKF_ERR_INVALID, "B must be <= 65535 (grid dimension)");
+    ekf_batch_s* f = new (std::nothrow) ekf_batch_s();
+    if (!f) return fail(EKF_ERR_NOMEM, "host allocation failed");
+    ekf_status st = f->pool.create(B, n, params, device);
+    if (st != EKF_OK) {
+        f->pool.destroy();
+        delete f;
+        return st;
+    }
+    *out = f;
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_destroy(ekf_batch_handle hb) {
+    if (!hb) return EKF_OK;
+    hb->pool.destroy();
+    delete hb;
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_reset(ekf_batch_handle hb) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    return hb->pool.reset();
+}
+
+ekf_status ekf_batch_device_bytes(ekf_batch_handle hb, size_t* bytes) {
+    if (!hb || !bytes) return fail(EKF_ERR_INVALID, "null argument");
+    *bytes = hb->pool.dev_bytes + hb->pool.log_bytes;
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    hb->pool.tuning = ekf::Rank2Tuning{rows_per_block, nontemporal};
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_upload_known_log(ekf_batch_handle hb, const ekf_known_log* log) {
+    if (!hb || !log || !log->twist || !log->lm_idx || !log->z_xy || !log->init_xy || log->T <= 0 || log->vmax < 0)
+        return fail(EKF_ERR_INVALID, "ekf_batch_upload_known_log: bad argument");
+    Pool& P = hb->pool;
+    EKFC(P.use());
+    const int B = P.pv.B, n = P.pv.n, T = log->T, vmax = log->vmax;
+    // validate: indices in range, ascending within a step (the loop order of ekf_slam.cpp:132)
+    std::vector<int> active((size_t)T * (vmax > 0 ? vmax : 1), 0);
+    for (int t = 0; t < T; t++)
+        for (int b = 0; b < B; b++) {
+            int prev = -1;
+            bool ended = false;
+            for (int v = 0; v < vmax; v++) {
+                const int lm = log->lm_idx[((size_t)t * B + b) * vmax + v];
+                if (lm < 0) { ended = true; continue; }
+                if (ended || lm >= n || lm <= prev)
+                    return fail(EKF_ERR_INVALID, "known log: landmark indices must be < n, strictly ascending, -1 padded");
+                prev = lm;
+                active[(size_t)t * vmax + v]++;
+            }
+        }
+    HIPC(hipStreamSynchronize(P.stream));
+    for (void* p : {(void*)P.log_twist, (void*)P.log_lm, (void*)P.log_z, (void*)P.log_init})
+        if (p) HIPC(hipFree(p));
+    P.log_twist = nullptr; P.log_lm = nullptr; P.log_z = nullptr; P.log_init = nullptr;
+    const size_t n_tw = (size_t)T * B * 2, n_lm = (size_t)T * B * vmax, n_z = n_lm * 2, n_in = (size_t)B * 2 * n;
+    HIPC(hipMalloc((void**)&P.log_twist, sizeof(double) * (n_tw ? n_tw : 1)));
+    HIPC(hipMalloc((void**)&P.log_lm, sizeof(int) * (n_lm ? n_lm : 1)));
+    HIPC(hipMalloc((void**)&P.log_z, sizeof(double) * (n_z ? n_z : 1)));
+    HIPC(hipMalloc((void**)&P.log_init, sizeof(double) * (n_in ? n_in : 1)));
+    P.log_bytes = sizeof(double) * (n_tw + n_z + n_in) + sizeof(int) * n_lm;
+    HIPC(hipMemcpy(P.log_twist, log->twist, sizeof(double) * n_tw, hipMemcpyHostToDevice));
+    if (n_lm) HIPC(hipMemcpy(P.log_lm, log->lm_idx, sizeof(int) * n_lm, hipMemcpyHostToDevice));
+    if (n_z) HIPC(hipMemcpy(P.log_z, log->z_xy, sizeof(double) * n_z, hipMemcpyHostToDevice));
+    if (n_in) HIPC(hipMemcpy(P.log_init, log->init_xy, sizeof(double) * n_in, hipMemcpyHostToDevice));
+    P.T = T;
+    P.vmax = vmax;
+    P.slot_active.swap(active);
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int time_kernels, ekf_run_stats* stats) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    Pool& P = hb->pool;
+    if (P.T <= 0) return fail(EKF_ERR_STATE, "ekf_batch_run_known: no log uploaded");
+    if (t_begin < 0 || t_end > P.T || t_begin > t_end) return fail(EKF_ERR_INVALID, "step range outside the uploaded log");
+    EKFC(P.use());
+    const int B = P.pv.B, vmax = P.vmax;
+    size_t launches = 0;
+    long long corrections = 0;
+    for (int t = t_begin; t < t_end; t++)
+        for (int v = 0; v < vmax; v++)
+            if (P.slot_active[(size_t)t * vmax + v] > 0) {
+                launches++;
+                corrections += P.slot_active[(size_t)t * vmax + v];
+            }
+    hipEvent_t* ev = nullptr;
+    if (time_kernels && launches) {
+        ev = P.events(2 * launches);
+        if (!ev) return fail(EKF_ERR_HIP, "hipEventCreate failed");
+    }
+    HIPC(hipEventRecord(P.ev_begin, P.stream));
+    size_t k = 0;
+    ekf::CmdSrc src{};
+    src.mode = ekf::SRC_COMPACT_LOG;
+    src.vmax = vmax;
+    src.fresh_pose = 0;
+    for (int t = t_begin; t < t_end; t++) {
+        ekf::launch_predict(P.pv, P.log_twist + (size_t)t * B * 2, 0.0, 0.0, P.stream);  // prediction()
+        ekf::launch_measure_begin(P.pv, P.log_init, !P.init_flag, P.stream);               // measurement() top
+        P.init_flag = 1;
+        src.lm_idx = P.log_lm + (size_t)t * B * vmax;
+        src.z_xy = P.log_z + (size_t)t * B * vmax * 2;
+        for (int v = 0; v < vmax; v++) {
+            if (P.slot_active[(size_t)t * vmax + v] == 0) continue;
+            src.v = v;
+            ekf::launch_gain(P.pv, src, P.stream);
+            if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
+            ekf::launch_rank2(P.pv, P.tuning, P.stream);
+            if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
+            k++;
+        }
+    }
+    HIPC(hipEventRecord(P.ev_end, P.stream));
+    EKFC(checked_launch());
+    HIPC(hipStreamSynchronize(P.stream));
+    if (stats) {
+        float ms = 0.f;
+        HIPC(hipEventElapsedTime(&ms, P.ev_begin, P.ev_end));
+        stats->elapsed_ms = ms;
+        stats->rank2_ms = 0.0;
+        stats->rank2_launches = (long long)launches;
+        if (ev)
+            for (size_t i = 0; i < launches; i++) {
+                float m = 0.f;
+                HIPC(hipEventElapsedTime(&m, ev[2 * i], ev[2 * i + 1]));
+                stats->rank2_ms += m;
+            }
+        stats->corrections = corrections;
+        stats->filter_steps = (long long)B * (t_end - t_begin);
+        const double per_corr = 2.0 * sizeof(double) * (double)P.pv.N * (double)P.pv.N;
+        stats->rank2_bytes_per_launch = launches ? per_corr * (double)corrections / (double)launches : 0.0;
+    }
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_get_state(ekf_batch_handle hb, int b, double* out) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    return hb->pool.get_state(b, out);
+}
+
+ekf_status ekf_batch_get_cov(ekf_batch_handle hb, int b, double* out) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    return hb->pool.get_cov(b, out);
+}
+
+ekf_status ekf_batch_get_poses(ekf_batch_handle hb, double* out) {
+    if (!hb || !out) return fail(EKF_ERR_INVALID, "null argument");
+    Pool& P = hb->pool;
+    EKFC(P.use());
+    ekf::launch_gather_poses(P.pv, P.poses_dev, P.stream);
+    EKFC(checked_launch());
+    return P.download(out, P.poses_dev, sizeof(double) * 3 * P.pv.B);
+}
+
+ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]) {
+    if (!hb || !out) return fail(EKF_ERR_INVALID, "null argument");
+    Pool& P = hb->pool;
+    EKFC(P.use());
+    HIPC(hipMemsetAsync(P.digest_dev, 0, sizeof(double) * 4 * P.pv.B, P.stream));
+    ekf::launch_checksum(P.pv, P.digest_dev, P.stream);
+    EKFC(checked_launch());
+    std::vector<double> h((size_t)4 * P.pv.B);
+    EKFC(P.download(h.data(), P.digest_dev, sizeof(double) * h.size()));
+    for (int k = 0; k < 4; k++) out[k] = 0.0;
+    for (int b = 0; b < P.pv.B; b++)
+        for (int k = 0; k < 4; k++) out[k] += h[(size_t)b * 4 + k];
+    return EKF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,585 @@
+// ekf_kernels.hip -- hand-written gfx950 kernels for the rigid2d::EKF_SLAM hot path.
+// See ekf_kernels.hpp for the HBM layout.  Reference line numbers are rigid2d/src/ekf_slam.cpp.
+#include "ekf_kernels.hpp"
+
+#include <limits.h>
+
+namespace ekf {
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int idx5(int k, int lm) { return k < 3 ? k : 3 + 2 * lm + (k - 3); }
+
+// ---------------------------------------------------------------------------------------------
+// Constructor state, ekf_slam.cpp:27-53: Sigma0 = blockdiag(0_3x3, sigma0 * I_2n), state = 0.
+// grid (row blocks, B); 256 threads; each block writes 8 rows with 16-B stores.
+// ---------------------------------------------------------------------------------------------
+constexpr int kInitRows = 8;
+
+__global__ __launch_bounds__(256) void k_init(PoolView pv) {
+    const int b = blockIdx.y;
+    const int ld2 = pv.ld >> 1;
+    double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    const int r0 = blockIdx.x * kInitRows;
+    for (int rr = 0; rr < kInitRows; rr++) {
+        const int r = r0 + rr;
+        if (r >= pv.N) break;
+        double2_t* row = reinterpret_cast<double2_t*>(Sg + (size_t)r * pv.ld);
+        for (int c2 = threadIdx.x; c2 < ld2; c2 += 256) {
+            double2_t v = {0.0, 0.0};
+            if (r >= 3) {
+                if (2 * c2 == r) v.x = 1.0 * pv.p.sigma0_landmark;
+                if (2 * c2 + 1 == r) v.y = 1.0 * pv.p.sigma0_landmark;
+            }
+            row[c2] = v;
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < pv.ld; i += 256) {
+            pv.state[(size_t)b * pv.ld + i] = 0.0;
+            pv.Kg[(size_t)b * 2 * pv.ld + i] = 0.0;
+            pv.Kg[(size_t)b * 2 * pv.ld + pv.ld + i] = 0.0;
+            pv.Gh[(size_t)b * 2 * pv.ld + i] = 0.0;
+            pv.Gh[(size_t)b * 2 * pv.ld + pv.ld + i] = 0.0;
+        }
+        if (threadIdx.x < 4) pv.snap[(size_t)b * 4 + threadIdx.x] = 0.0;
+        if (threadIdx.x == 0) {
+            pv.rec[b] = CorrRec{0.0, 0.0, 0, -1};
+            pv.assoc[b] = AssocRec{0, -1, 0, 0, 0.0};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// prediction(), ekf_slam.cpp:55-106.  At = I + A has two off-diagonal non-zeros (A(1,0), A(2,0),
+// :85-86/:93-94), so At*Sigma*At^T + Q only changes rows 1,2 and columns 1,2 of Sigma: O(N) work,
+// about 10*8*N bytes instead of two N^3 DGEMMs.  One workgroup per filter: every thread needs the
+// OLD theta before thread 0 overwrites the pose, and __syncthreads() is the only fence needed.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPredictThreads = 1024;
+
+__global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const double* twist_dev, double dth_imm,
+                                                            double dx_imm) {
+    const int b = blockIdx.x;
+    const int N = pv.N, ld = pv.ld;
+    double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    double* st = pv.state + (size_t)b * ld;
+    const double dtheta = twist_dev ? twist_dev[(size_t)b * 2 + 0] : dth_imm;  // twist.angular()  :67
+    const double dx = twist_dev ? twist_dev[(size_t)b * 2 + 1] : dx_imm;       // twist.linearX()  :69
+    const double theta = st[0];
+    double u0, u1, u2, a10, a20;
+    if (fabs(dtheta) < pv.p.straight_eps) {  // :79-86
+        u0 = 0;
+        u1 = dx * cos(theta);
+        u2 = dx * sin(theta);
+        a10 = -dx * sin(theta);
+        a20 = dx * cos(theta);
+    } else {  // :88-94
+        u0 = dtheta;
+        u1 = -(dx / dtheta) * sin(theta) + (dx / dtheta) * sin(theta + dtheta);
+        u2 = (dx / dtheta) * cos(theta) - (dx / dtheta) * cos(theta + dtheta);
+        a10 = -(dx / dtheta) * cos(theta) + (dx / dtheta) * cos(theta + dtheta);
+        a20 = -(dx / dtheta) * sin(theta) + (dx / dtheta) * sin(theta + dtheta);
+    }
+    __syncthreads();  // all threads hold the old theta; thread 0 may now move the pose
+
+    for (int k = 3 + threadIdx.x; k < N; k += kPredictThreads) {
+        const double s0 = Sg[k];                      // row 0 (coalesced)
+        const double s1 = Sg[(size_t)1 * ld + k];
+        const double s2 = Sg[(size_t)2 * ld + k];
+        double* rowk = Sg + (size_t)k * ld;           // columns 0..2 of row k (one 32-B sector)
+        const double r0 = rowk[0], r1 = rowk[1], r2 = rowk[2];
+        Sg[(size_t)1 * ld + k] = a10 * s0 + s1;
+        Sg[(size_t)2 * ld + k] = a20 * s0 + s2;
+        rowk[1] = r0 * a10 + r1;
+        rowk[2] = r0 * a20 + r2;
+    }
+    if (threadIdx.x == 0) {
+        st[0] = theta + u0;  // :99 -- theta is NOT wrapped after the prediction
+        st[1] = st[1] + u1;
+        st[2] = st[2] + u2;
+        double c[3][3], T[3][3];
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) c[r][k] = Sg[(size_t)r * ld + k];
+        for (int k = 0; k < 3; k++) {
+            T[0][k] = c[0][k];
+            T[1][k] = a10 * c[0][k] + c[1][k];
+            T[2][k] = a20 * c[0][k] + c[2][k];
+        }
+        for (int r = 0; r < 3; r++) {
+            Sg[(size_t)r * ld + 0] = T[r][0];
+            Sg[(size_t)r * ld + 1] = T[r][0] * a10 + T[r][1];
+            Sg[(size_t)r * ld + 2] = T[r][0] * a20 + T[r][2];
+        }
+        Sg[0] += pv.p.q_pose;  // Q = diag(q,q,q,0...) :40-43
+        Sg[(size_t)1 * ld + 1] += pv.p.q_pose;
+        Sg[(size_t)2 * ld + 2] += pv.p.q_pose;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Top of measurement(), ekf_slam.cpp:109-128: capture (theta,x,y) once -- the per-landmark loop
+// keeps using this STALE pose -- and, on the first call only, initialise ALL n landmarks from the
+// sensor vector regardless of visibility.  grid (ceil(n/256), B).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_measure_begin(PoolView pv, const double* init_xy, int do_init) {
+    const int b = blockIdx.y;
+    double* st = pv.state + (size_t)b * pv.ld;
+    const double theta = st[0], x = st[1], y = st[2];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double* sn = pv.snap + (size_t)b * 4;
+        sn[0] = theta; sn[1] = x; sn[2] = y;
+    }
+    if (do_init) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < pv.n) {
+            const double sx = init_xy[(size_t)b * 2 * pv.n + 2 * i];
+            const double sy = init_xy[(size_t)b * 2 * pv.n + 2 * i + 1];
+            const double ri = sqrt(sx * sx + sy * sy);
+            const double phii = atan2(sy, sx);
+            st[2 * i + 3] = x + ri * cos(phii + theta);
+            st[2 * i + 3 + 1] = y + ri * sin(phii + theta);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gain kernel: everything of one landmark correction (ekf_slam.cpp:137-187) except the O(N^2)
+// covariance stream.  H has 5 non-zero columns c5 = {0,1,2,3+2i,4+2i}, so
+//   S  = H5 * Sigma[c5,c5] * H5^T + R           (25 covariance entries)
+//   K  = Sigma[:,c5] * H5^T * S^-1              (5 strided column reads per row)
+//   G  = H5 * Sigma[c5,:]                       (5 coalesced row reads per column)
+// Reads Sigma/state only, writes scratch (Kg, Gh, rec) only -> race-free across workgroups; the
+// state update state += K*nu (:186-187) happens in the rank-2 kernel, after the kernel boundary.
+// grid (ceil(ld/256), B), 256 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int N = pv.N, ld = pv.ld;
+    __shared__ double sh_S55[25];
+    __shared__ double sh_H[10];
+    __shared__ double sh_Si[4];
+
+    int lm = -1;
+    double sx = 0.0, sy = 0.0;
+    if (src.mode == SRC_SENSOR_VECTOR) {
+        lm = src.lm_imm;
+        sx = src.sensor[(size_t)b * 2 * pv.n + 2 * lm];
+        sy = src.sensor[(size_t)b * 2 * pv.n + 2 * lm + 1];
+    } else if (src.mode == SRC_COMPACT_LOG) {
+        const size_t slot = (size_t)b * src.vmax + src.v;
+        lm = src.lm_idx[slot];
+        if (lm >= 0) {
+            sx = src.z_xy[slot * 2];
+            sy = src.z_xy[slot * 2 + 1];
+        }
+    } else {
+        const AssocRec a = src.assoc[b];
+        lm = a.active ? a.lm : -1;
+        sx = src.meas[(size_t)b * 2];
+        sy = src.meas[(size_t)b * 2 + 1];
+    }
+    if (lm < 0 || lm >= pv.n) {  // nothing to correct for this filter in this slot
+        if (blockIdx.x == 0 && tid == 0) pv.rec[b].active = 0;
+        return;
+    }
+
+    const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    const double* st = pv.state + (size_t)b * ld;
+    if (tid < 25) sh_S55[tid] = Sg[(size_t)idx5(tid / 5, lm) * ld + idx5(tid % 5, lm)];
+    __syncthreads();
+    if (tid == 0) {
+        double theta, x, y;
+        if (src.fresh_pose) {  // data_association re-reads the pose per measurement, :331-333
+            theta = st[0]; x = st[1]; y = st[2];
+        } else {               // measurement() keeps the pose captured at :109-111
+            const double* sn = pv.snap + (size_t)b * 4;
+            theta = sn[0]; x = sn[1]; y = sn[2];
+        }
+        MeasTerms m;
+        measurement_terms(st[2 * lm + 3], st[2 * lm + 4], sx, sy, theta, x, y, m);
+        double S55[5][5], S[2][2], Si[2][2];
+        for (int k = 0; k < 5; k++)
+            for (int l = 0; l < 5; l++) S55[k][l] = sh_S55[k * 5 + l];
+        innovation_cov(S55, m.H, pv.p.r_meas, S);
+        inv2(S, Si);
+        for (int a = 0; a < 2; a++)
+            for (int k = 0; k < 5; k++) sh_H[a * 5 + k] = m.H[a][k];
+        sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
+        if (blockIdx.x == 0) {
+            CorrRec r;
+            r.nu0 = m.z0 - m.zh0;                    // :182
+            r.nu1 = normalize_angle(m.z1 - m.zh1);   // :183
+            r.active = 1;
+            r.lm = lm;
+            pv.rec[b] = r;
+        }
+    }
+    __syncthreads();
+
+    const int r = blockIdx.x * 256 + tid;
+    if (r >= ld) return;
+    double k0 = 0.0, k1 = 0.0, g0 = 0.0, g1 = 0.0;
+    if (r < N) {
+        double sht0 = 0.0, sht1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int c = idx5(k, lm);
+            const double p = Sg[(size_t)r * ld + c];  // column gather (Sigma * H^T reads columns)
+            const double g = Sg[(size_t)c * ld + r];  // row gather    (H * Sigma reads rows)
+            sht0 += p * sh_H[k];
+            sht1 += p * sh_H[5 + k];
+            g0 += sh_H[k] * g;
+            g1 += sh_H[5 + k] * g;
+        }
+        k0 = sht0 * sh_Si[0] + sht1 * sh_Si[2];  // K = (Sigma H^T) S^-1   :178
+        k1 = sht0 * sh_Si[1] + sht1 * sh_Si[3];
+    }
+    double* Kg = pv.Kg + (size_t)b * 2 * ld;
+    double* Gh = pv.Gh + (size_t)b * 2 * ld;
+    Kg[r] = k0;
+    Kg[ld + r] = k1;
+    Gh[r] = g0;
+    Gh[ld + r] = g1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rank-2 covariance correction, the bandwidth-bound core: Sigma <- (I - K H) Sigma
+// (ekf_slam.cpp:191-192) evaluated as Sigma[r][c] -= K[r][0]*G[0][c] + K[r][1]*G[1][c].
+// Algorithmic traffic 2*8*N^2 bytes (read + write Sigma once), 4 N^2 flop -> HBM-bound.
+//
+// Workgroup = 256 threads as TX column lanes x TY = 256/TX row lanes.  A thread owns CH double2
+// columns (stride TX) whose G values live in registers for the whole row loop, and streams
+// rows_per_block rows with 16-B loads/stores (every wave instruction moves 1 KiB contiguous when
+// TX >= 64).  K[r][*] is uniform per row.  The same workgroups apply state += K*nu (:186) and the
+// theta wrap (:187).  grid (col blocks, row blocks, B).
+// ---------------------------------------------------------------------------------------------
+template <bool NT>
+__device__ __forceinline__ double2_t ld2(const double2_t* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st2(double2_t* p, double2_t v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <int TX, int CH, bool NT>
+__global__ __launch_bounds__(256) void k_rank2(PoolView pv, int rows_per_block) {
+    constexpr int TY = 256 / TX;
+    const int b = blockIdx.z;
+    if (!pv.rec[b].active) return;
+    const int N = pv.N, ld = pv.ld, ld2n = ld >> 1;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int cbase = blockIdx.x * (TX * CH) + tx;
+    const double* Kg = pv.Kg + (size_t)b * 2 * ld;
+    const double2_t* G0 = reinterpret_cast<const double2_t*>(pv.Gh + (size_t)b * 2 * ld);
+    const double2_t* G1 = reinterpret_cast<const double2_t*>(pv.Gh + (size_t)b * 2 * ld + ld);
+    double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+
+    double2_t g0[CH], g1[CH];
+    bool ok[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        const int c2 = cbase + ch * TX;
+        ok[ch] = c2 < ld2n;
+        g0[ch] = ok[ch] ? G0[c2] : double2_t{0.0, 0.0};
+        g1[ch] = ok[ch] ? G1[c2] : double2_t{0.0, 0.0};
+    }
+
+    const int row_begin = blockIdx.y * rows_per_block;
+    const int row_end = min(N, row_begin + rows_per_block);
+    int r = row_begin + ty;
+    // two rows per trip: 2*CH independent 16-B loads in flight per lane before the first use
+    for (; r + TY < row_end; r += 2 * TY) {
+        const int ra = r, rb = r + TY;
+        const double ka0 = Kg[ra], ka1 = Kg[ld + ra];
+        const double kb0 = Kg[rb], kb1 = Kg[ld + rb];
+        double2_t* rowa = reinterpret_cast<double2_t*>(Sg + (size_t)ra * ld);
+        double2_t* rowb = reinterpret_cast<double2_t*>(Sg + (size_t)rb * ld);
+        double2_t va[CH], vb[CH];
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++)
+            if (ok[ch]) va[ch] = ld2<NT>(rowa + cbase + ch * TX);
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++)
+            if (ok[ch]) vb[ch] = ld2<NT>(rowb + cbase + ch * TX);
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++)
+            if (ok[ch]) {
+                va[ch].x = va[ch].x - (ka0 * g0[ch].x + ka1 * g1[ch].x);
+                va[ch].y = va[ch].y - (ka0 * g0[ch].y + ka1 * g1[ch].y);
+                st2<NT>(rowa + cbase + ch * TX, va[ch]);
+            }
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++)
+            if (ok[ch]) {
+                vb[ch].x = vb[ch].x - (kb0 * g0[ch].x + kb1 * g1[ch].x);
+                vb[ch].y = vb[ch].y - (kb0 * g0[ch].y + kb1 * g1[ch].y);
+                st2<NT>(rowb + cbase + ch * TX, vb[ch]);
+            }
+    }
+    for (; r < row_end; r += TY) {
+        const double k0 = Kg[r], k1 = Kg[ld + r];
+        double2_t* row = reinterpret_cast<double2_t*>(Sg + (size_t)r * ld);
+        double2_t v[CH];
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++)
+            if (ok[ch]) v[ch] = ld2<NT>(row + cbase + ch * TX);
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++)
+            if (ok[ch]) {
+                v[ch].x = v[ch].x - (k0 * g0[ch].x + k1 * g1[ch].x);
+                v[ch].y = v[ch].y - (k0 * g0[ch].y + k1 * g1[ch].y);
+                st2<NT>(row + cbase + ch * TX, v[ch]);
+            }
+    }
+
+    // state = state + Ki*z_diff (:186); state(0) = normalize_angle(state(0)) (:187)
+    if (blockIdx.x == 0) {
+        const CorrRec rc = pv.rec[b];
+        double* st = pv.state + (size_t)b * ld;
+        for (int rr = row_begin + (int)threadIdx.x; rr < row_end; rr += 256) {
+            double s = st[rr] + (Kg[rr] * rc.nu0 + Kg[ld + rr] * rc.nu1);
+            if (rr == 0) s = normalize_angle(s);
+            st[rr] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mahalanobis scores, calculate_maha_dis() ekf_slam.cpp:217-276: ONE LANDMARK PER WAVEFRONT.
+// 25 lanes fetch the 5x5 sub-block Sigma[c5,c5] in one go; H*Sigma*H^T is folded with wave
+// shuffles in the CPU restatement's summation order; the innovation bearing is NOT wrapped (:269).
+// grid (ceil(n/4), B), 4 waves per workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_maha(PoolView pv, const double* meas, double* scores, int m_override) {
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int i = blockIdx.x * 4 + wave;
+    const int M = m_override >= 0 ? m_override : pv.assoc[b].known_count;
+    if (i >= M || i >= pv.n) return;  // wave-uniform
+    const int ld = pv.ld;
+    const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    const double* st = pv.state + (size_t)b * ld;
+
+    double v = 0.0;
+    if (lane < 25) v = Sg[(size_t)idx5(lane / 5, i) * ld + idx5(lane % 5, i)];
+
+    MeasTerms m;  // fresh pose per score, :219-221
+    measurement_terms(st[2 * i + 3], st[2 * i + 4], meas[(size_t)b * 2], meas[(size_t)b * 2 + 1], st[0], st[1], st[2], m);
+
+    // lanes l = 0..4 build column l of H*Sigma[c5,c5]
+    const int l5 = lane < 5 ? lane : 4;
+    double hs0 = 0.0, hs1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const double vk = __shfl(v, k * 5 + l5, kWave);
+        hs0 += m.H[0][k] * vk;
+        hs1 += m.H[1][k] * vk;
+    }
+    double S[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+    for (int l = 0; l < 5; l++) {
+        const double h0 = __shfl(hs0, l, kWave), h1 = __shfl(hs1, l, kWave);
+        S[0][0] += h0 * m.H[0][l];
+        S[0][1] += h0 * m.H[1][l];
+        S[1][0] += h1 * m.H[0][l];
+        S[1][1] += h1 * m.H[1][l];
+    }
+    S[0][0] += pv.p.r_meas;
+    S[1][1] += pv.p.r_meas;
+    double Si[2][2];
+    inv2(S, Si);
+    const double v0 = m.z0 - m.zh0, v1 = m.z1 - m.zh1;
+    const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
+    const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
+    if (lane == 0) scores[(size_t)b * pv.n + i] = t0 * v0 + t1 * v1;
+}
+
+__global__ void k_assoc_begin(PoolView pv, const int* known_count_dev, int known_count_imm) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= pv.B) return;
+    AssocRec a;
+    a.known_count = known_count_dev ? known_count_dev[b] : known_count_imm;
+    a.lm = -1; a.active = 0; a.pad = 0; a.best = 0.0;
+    pv.assoc[b] = a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decision step of data_association() for one measurement, ekf_slam.cpp:293-330: sequential-scan
+// semantics (first index attaining the strict minimum below gate_new) as a lexicographic (d, i)
+// min-reduction; NaN scores never win (`d < min` is false).  New landmark initialisation
+// (:200-214, :318-327) and the gate_update test (:330) run on one lane.  grid (B), 256 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assoc_decide(PoolView pv, const double* meas, const double* scores,
+                                                      int* assoc_out, int out_stride, int j) {
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ double sh_d[4];
+    __shared__ int sh_i[4];
+    const int M = pv.assoc[b].known_count;
+    double best = pv.p.gate_new;  // :293
+    int bi = INT_MAX;
+    for (int i = tid; i < M; i += 256) {
+        const double d = scores[(size_t)b * pv.n + i];
+        if (d < best) { best = d; bi = i; }  // :305-309
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_down(best, off, kWave);
+        const int oi = __shfl_down(bi, off, kWave);
+        if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sh_d[tid >> 6] = best; sh_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++)
+            if (sh_d[w] < best || (sh_d[w] == best && sh_i[w] < bi)) { best = sh_d[w]; bi = sh_i[w]; }
+        int idx = (bi == INT_MAX) ? M : bi;  // :294 min_maha_idx = known_count
+        int known_count = M;
+        double* st = pv.state + (size_t)b * pv.ld;
+        if (idx == M && idx < pv.n) {  // :318-327 new landmark
+            const double theta = st[0], x = st[1], y = st[2];
+            const double sx = meas[(size_t)b * 2], sy = meas[(size_t)b * 2 + 1];
+            const double ri = sqrt(sx * sx + sy * sy);
+            const double phii = atan2(sy, sx);
+            st[2 * idx + 3] = x + ri * cos(phii + theta);
+            st[2 * idx + 3 + 1] = y + ri * sin(phii + theta);
+            known_count = M + 1;
+            best = 0.0;
+        }
+        // :330.  idx == n (map full, no match) can only pass the gate with non-reference
+        // parameters (gate_new < gate_update); the reference would index out of bounds there.
+        const int active = (best < pv.p.gate_update) && idx < pv.n;
+        AssocRec a;
+        a.known_count = known_count;
+        a.lm = active ? idx : -1;
+        a.active = active;
+        a.pad = 0;
+        a.best = best;
+        pv.assoc[b] = a;
+        if (assoc_out) assoc_out[(size_t)b * out_stride + j] = a.lm;
+    }
+}
+
+// per-filter digest {sum state, sum |state|, sum sigma, sum |sigma|} -> out[b][4] (atomics)
+__global__ __launch_bounds__(256) void k_checksum(PoolView pv, double* out) {
+    const int b = blockIdx.y;
+    const int N = pv.N, ld = pv.ld;
+    const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    double s = 0.0, sa = 0.0, t = 0.0, ta = 0.0;
+    for (int r = blockIdx.x; r < N; r += gridDim.x) {
+        for (int c = threadIdx.x; c < N; c += 256) {
+            const double v = Sg[(size_t)r * ld + c];
+            t += v; ta += fabs(v);
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < N; c += 256) {
+            const double v = pv.state[(size_t)b * ld + c];
+            s += v; sa += fabs(v);
+        }
+    __shared__ double sh[4][4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, kWave); sa += __shfl_down(sa, off, kWave);
+        t += __shfl_down(t, off, kWave); ta += __shfl_down(ta, off, kWave);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6][0] = s; sh[threadIdx.x >> 6][1] = sa;
+        sh[threadIdx.x >> 6][2] = t; sh[threadIdx.x >> 6][3] = ta;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const double v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        atomicAdd(out + (size_t)b * 4 + threadIdx.x, v);
+    }
+}
+
+__global__ void k_gather_poses(PoolView pv, double* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= pv.B) return;
+    for (int k = 0; k < 3; k++) out[(size_t)b * 3 + k] = pv.state[(size_t)b * pv.ld + k];
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+
+void launch_init(const PoolView& pv, hipStream_t s) {
+    dim3 grid((pv.N + kInitRows - 1) / kInitRows, pv.B);
+    hipLaunchKernelGGL(k_init, grid, dim3(256), 0, s, pv);
+}
+
+void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, double dx, hipStream_t s) {
+    hipLaunchKernelGGL(k_predict, dim3(pv.B), dim3(kPredictThreads), 0, s, pv, twist_dev, dtheta, dx);
+}
+
+void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init, hipStream_t s) {
+    const int gx = do_init ? (pv.n + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_measure_begin, dim3(gx > 0 ? gx : 1, pv.B), dim3(256), 0, s, pv, init_xy, do_init);
+}
+
+void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s) {
+    hipLaunchKernelGGL(k_gain, dim3((pv.ld + 255) / 256, pv.B), dim3(256), 0, s, pv, src);
+}
+
+template <int TX, int CH>
+static void launch_rank2_t(const PoolView& pv, int rows, bool nt, hipStream_t s) {
+    const int ld2n = pv.ld / 2;
+    dim3 grid((ld2n + TX * CH - 1) / (TX * CH), (pv.N + rows - 1) / rows, pv.B);
+    if (nt) hipLaunchKernelGGL((k_rank2<TX, CH, true>), grid, dim3(256), 0, s, pv, rows);
+    else hipLaunchKernelGGL((k_rank2<TX, CH, false>), grid, dim3(256), 0, s, pv, rows);
+}
+
+void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s) {
+    const int ld2n = pv.ld / 2;
+    // Non-temporal only when the pool cannot stay resident in the 256 MiB Infinity Cache between
+    // two corrections; a single filter's covariance (32 MB at n = 1000) should stay cached.
+    const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
+    const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
+    int rows = t.rows_per_block;
+    const int ty = ld2n <= 256 ? 4 : 1;  // TX = 64 -> 4 row lanes
+    if (rows <= 0) {
+        // enough workgroups to fill 256 CUs several times over, but rows long enough to amortise
+        // the per-workgroup G fetch
+        const long long total_rows = (long long)pv.B * pv.N;
+        rows = total_rows >= 256LL * 8 * 16 ? 16 : (total_rows >= 256LL * 8 * 4 ? 4 : 2);
+        rows *= ty;
+    }
+    if (rows > 256) rows = 256;
+    if (rows < ty) rows = ty;
+    if (ld2n <= 64) launch_rank2_t<64, 1>(pv, rows, nt, s);
+    else if (ld2n <= 128) launch_rank2_t<64, 2>(pv, rows, nt, s);
+    else if (ld2n <= 192) launch_rank2_t<64, 3>(pv, rows, nt, s);
+    else if (ld2n <= 256) launch_rank2_t<64, 4>(pv, rows, nt, s);
+    else if (ld2n <= 512) launch_rank2_t<256, 2>(pv, rows, nt, s);
+    else if (ld2n <= 768) launch_rank2_t<256, 3>(pv, rows, nt, s);
+    else launch_rank2_t<256, 4>(pv, rows, nt, s);
+}
+
+void launch_maha(const PoolView& pv, const double* meas, double* scores, int m_override, hipStream_t s) {
+    if (pv.n <= 0) return;
+    hipLaunchKernelGGL(k_maha, dim3((pv.n + 3) / 4, pv.B), dim3(256), 0, s, pv, meas, scores, m_override);
+}
+
+void launch_assoc_begin(const PoolView& pv, const int* known_count_dev, int known_count_imm, hipStream_t s) {
+    hipLaunchKernelGGL(k_assoc_begin, dim3((pv.B + 255) / 256), dim3(256), 0, s, pv, known_count_dev, known_count_imm);
+}
+
+void launch_assoc_decide(const PoolView& pv, const double* meas, const double* scores, int* assoc_out,
+                         int out_stride, int j, hipStream_t s) {
+    hipLaunchKernelGGL(k_assoc_decide, dim3(pv.B), dim3(256), 0, s, pv, meas, scores, assoc_out, out_stride, j);
+}
+
+void launch_checksum(const PoolView& pv, double* out, hipStream_t s) {
+    const int gx = pv.N < 64 ? pv.N : 64;
+    hipLaunchKernelGGL(k_checksum, dim3(gx, pv.B), dim3(256), 0, s, pv, out);
+}
+
+void launch_gather_poses(const PoolView& pv, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_poses, dim3((pv.B + 255) / 256), dim3(256), 0, s, pv, out);
+}
+
+}  // namespace ekf

@@ -1,0 +1,157 @@
+// ekf_kernels.hpp -- gfx950 (CDNA4, wave64) kernels of the EKF-SLAM filter core.
+//
+// Every kernel serves a POOL of B independent filters (B = 1 for a single rigid2d::EKF_SLAM
+// object); blockIdx.z (or .y) selects the filter.  HBM layout per filter b:
+//   sigma  [N][ld]   fp64 row-major, ld = N rounded up to 16 doubles (rows start on 128-B lines,
+//                    so every lane moves aligned 16-B double2); pad columns stay 0
+//   state  [ld]      [theta, x, y, m1x, m1y, ...]                  (ekf_slam.cpp:15-21,72-74)
+//   Kg     [2][ld]   Kalman gain columns K(:,0), K(:,1)  (scratch between gain and rank-2 kernel)
+//   Gh     [2][ld]   rows of H*Sigma                      (pad entries 0)
+//   rec              per-filter correction record (innovation, active flag)
+//   snap   [4]       pose captured at the top of measurement()      (ekf_slam.cpp:109-111)
+//
+// Arithmetic is fp64 and is compiled with -ffp-contract=off so that the operation order is
+// exactly that of oracle/ekf_oracle.c mode 1 ("structured"); only sin/cos/atan2 (OCML vs glibc)
+// can differ in the last bits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ekf {
+
+constexpr double kPI = 3.14159265358979323846;  // rigid2d/include/rigid2d/rigid2d.hpp:13
+constexpr int kWave = 64;
+
+struct Params {
+    double sigma0_landmark, q_pose, r_meas, gate_new, gate_update, straight_eps;
+};
+
+// One per filter: what the gain kernel decided / computed for the rank-2 kernel.
+struct CorrRec {
+    double nu0, nu1;  // innovation, bearing wrapped (ekf_slam.cpp:182-183)
+    int active;       // 0 -> the rank-2 kernel skips this filter
+    int lm;           // landmark index being corrected
+};
+
+// Per-filter association state (data_association(), ekf_slam.cpp:278-402).
+struct AssocRec {
+    int known_count;  // leading run of known_list (:281-288), grows as landmarks are initialised
+    int lm;           // decision for the current measurement (-1 = dropped)
+    int active;
+    int pad;
+    double best;      // winning Mahalanobis distance (diagnostic)
+};
+
+// Where a correction's (landmark, reading) comes from.
+enum : int { SRC_SENSOR_VECTOR = 0, SRC_COMPACT_LOG = 1, SRC_ASSOC = 2 };
+struct CmdSrc {
+    int mode;
+    int lm_imm;             // SRC_SENSOR_VECTOR: landmark index (host loop over visible_list)
+    const double* sensor;   // SRC_SENSOR_VECTOR: [B][2n] sensor_reading
+    const int* lm_idx;      // SRC_COMPACT_LOG: slot table for this step, [B][vmax]
+    const double* z_xy;     // SRC_COMPACT_LOG: [B][vmax][2]
+    int vmax, v;
+    const AssocRec* assoc;  // SRC_ASSOC: per-filter decision
+    const double* meas;     // SRC_ASSOC: [B][2] current measurement
+    int fresh_pose;         // 1: read (theta,x,y) from state (:331-333); 0: from snap (:109-111)
+};
+
+struct PoolView {
+    double* sigma;
+    double* state;
+    double* Kg;
+    double* Gh;
+    double* snap;
+    CorrRec* rec;
+    AssocRec* assoc;
+    int n, N, ld, B;
+    size_t sigma_stride;  // doubles between consecutive filters' covariances = N * ld
+    Params p;
+};
+
+// rigid2d/src/rigid2d.cpp:336-345 -- double-fmod form, range (-pi, pi]
+__device__ __forceinline__ double normalize_angle(double rad) {
+    double reduced_ang = fmod(rad, (2 * kPI));
+    double ang = fmod((reduced_ang + (2 * kPI)), (2 * kPI));
+    if (ang > kPI) ang = ang - (2 * kPI);
+    return ang;
+}
+
+struct MeasTerms {
+    double z0, z1;      // (r, phi) of the reading               ekf_slam.cpp:142-146
+    double zh0, zh1;    // predicted (r, phi), bearing wrapped   ekf_slam.cpp:152-155
+    double H[2][5];     // non-zero columns {0,1,2,3+2i,4+2i}    ekf_slam.cpp:158-166
+};
+
+__device__ __forceinline__ void measurement_terms(double tx, double ty, double sx, double sy, double theta,
+                                                  double x, double y, MeasTerms& m) {
+    m.z0 = sqrt(sx * sx + sy * sy);
+    m.z1 = atan2(sy, sx);
+    double delta_x = tx - x, delta_y = ty - y;
+    double d = delta_x * delta_x + delta_y * delta_y;
+    m.zh0 = sqrt(d);
+    m.zh1 = normalize_angle(atan2(delta_y, delta_x) - theta);
+    double sd = sqrt(d);
+    m.H[0][0] = 0;  m.H[0][1] = -delta_x / sd; m.H[0][2] = -delta_y / sd;
+    m.H[1][0] = -1; m.H[1][1] = delta_y / d;   m.H[1][2] = -delta_x / d;
+    m.H[0][3] = delta_x / sd; m.H[0][4] = delta_y / sd;
+    m.H[1][3] = -delta_y / d; m.H[1][4] = delta_x / d;
+}
+
+// S = H Sigma H^T + R on the 5x5 sub-block, same summation order as the CPU restatement.
+__device__ __forceinline__ void innovation_cov(const double S55[5][5], const double H[2][5], double r_meas,
+                                               double S[2][2]) {
+    double HS5[2][5];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int l = 0; l < 5; l++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) s += H[a][k] * S55[k][l];
+            HS5[a][l] = s;
+        }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < 5; l++) s += HS5[a][l] * H[b][l];
+            S[a][b] = s;
+        }
+    S[0][0] += r_meas;
+    S[1][1] += r_meas;
+}
+
+__device__ __forceinline__ void inv2(const double S[2][2], double Si[2][2]) {
+    double det = S[0][0] * S[1][1] - S[0][1] * S[1][0];
+    Si[0][0] = S[1][1] / det;  Si[0][1] = -S[0][1] / det;
+    Si[1][0] = -S[1][0] / det; Si[1][1] = S[0][0] / det;
+}
+
+// ---- host-side launchers (ekf_kernels.hip) ---------------------------------------------------
+struct Rank2Tuning {
+    int rows_per_block;  // <= 0: automatic
+    int nontemporal;     // < 0: automatic
+};
+
+void launch_init(const PoolView& pv, hipStream_t s);
+// prediction(): twist = imm (dtheta, dx) when twist_dev == nullptr, else twist_dev[b*2 + {0,1}]
+void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, double dx, hipStream_t s);
+// top of measurement(): pose snapshot (+ first-call landmark initialisation from init_xy [B][2n])
+void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init, hipStream_t s);
+void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s);
+void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s);
+// data_association(): scores for landmarks [0, known_count) of every filter, one landmark per wavefront
+void launch_maha(const PoolView& pv, const double* meas /*[B][2]*/, double* scores /*[B][n]*/, int m_override,
+                 hipStream_t s);
+void launch_assoc_begin(const PoolView& pv, const int* known_count_dev, int known_count_imm, hipStream_t s);
+// decision for measurement j of every filter; assoc_out (nullable) gets [b*out_stride + j] = landmark or -1
+void launch_assoc_decide(const PoolView& pv, const double* meas, const double* scores, int* assoc_out,
+                         int out_stride, int j, hipStream_t s);
+// out[b][4] += {sum state, sum |state|, sum sigma, sum |sigma|}; caller zeroes out first
+void launch_checksum(const PoolView& pv, double* out, hipStream_t s);
+void launch_gather_poses(const PoolView& pv, double* out, hipStream_t s);
+
+}  // namespace ekf

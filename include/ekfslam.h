@@ -1,0 +1,156 @@
+/*
+ * ekfslam.h -- C ABI of libekfslam_hip.so, the MI355X (gfx950) EKF-SLAM filter core.
+ *
+ * Drop-in boundary for the hot path of tonylitianyu/EKF-SLAM-ML: the public class
+ * rigid2d::EKF_SLAM (rigid2d/include/rigid2d/ekf_slam.hpp:19-57, implemented in
+ * rigid2d/src/ekf_slam.cpp).  The reference has no FFI layer; the binding a maintainer
+ * adds is a replacement for src/ekf_slam.cpp that forwards each method to one entry
+ * point below (INTEGRATION.md shows it; host/ekf_slam.hpp is the header-only C++ mirror).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller-owned HOST buffers unless a name says _dev;
+ *   - every function returns an ekf_status (0 = EKF_OK); no exceptions cross the boundary;
+ *     ekf_last_error() gives the text of the calling thread's last failure;
+ *   - one handle = one filter (or one batch of filters) bound to one HIP device and one HIP
+ *     stream; a handle is NOT thread-safe (the reference is driven from ROS1's single-threaded
+ *     spinner, nuslam/src/slam.cpp:525);
+ *   - state order [theta, x, y, m1x, m1y, ...] (ekf_slam.cpp:15-21,72-74); N = 3 + 2n;
+ *   - covariance crosses the boundary ROW-major N x N fp64; std::vector<bool> arguments of the
+ *     reference cross as uint8_t[n] (0 / non-zero).
+ *   - all arithmetic is fp64 like the reference (arma::mat = Mat<double>).
+ */
+#ifndef EKFSLAM_H
+#define EKFSLAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    EKF_OK = 0,
+    EKF_ERR_INVALID = 1,   /* bad argument (null pointer, n < 0, index out of range ...) */
+    EKF_ERR_NO_DEVICE = 2, /* no HIP device / wrong architecture */
+    EKF_ERR_HIP = 3,       /* a HIP runtime call failed, see ekf_last_error() */
+    EKF_ERR_NOMEM = 4,     /* host or device allocation failed */
+    EKF_ERR_STATE = 5      /* call sequence error (e.g. run before a log was uploaded) */
+} ekf_status;
+
+/* The reference hard-codes these; defaults reproduce it exactly. */
+typedef struct {
+    double sigma0_landmark; /* 100     ekf_slam.cpp:32      initial landmark variance       */
+    double q_pose;          /* 1e-4    ekf_slam.cpp:40-43   process noise on theta, x, y    */
+    double r_meas;          /* 0.01    ekf_slam.cpp:172-175 range / bearing noise           */
+    double gate_new;        /* 10.0    ekf_slam.cpp:293     Mahalanobis gate: new landmark  */
+    double gate_update;     /* 1.0     ekf_slam.cpp:330     Mahalanobis gate: apply update  */
+    double straight_eps;    /* 1e-6    ekf_slam.cpp:79      |dtheta| below -> straight line */
+} ekf_params;
+
+typedef struct ekf_filter_s* ekf_handle;      /* one filter  == one rigid2d::EKF_SLAM object */
+typedef struct ekf_batch_s* ekf_batch_handle; /* B independent filters (Monte-Carlo batch)   */
+
+const char* ekf_last_error(void);
+void ekf_default_params(ekf_params* out);
+/* Number of visible HIP devices (0 if none); does not initialise a device context. */
+int ekf_device_count(void);
+
+/* ---- single filter: the rigid2d::EKF_SLAM call surface ------------------------------------ */
+
+/* EKF_SLAM::EKF_SLAM(int n_measurements)            ekf_slam.hpp:27, ekf_slam.cpp:27-53.
+ * params may be NULL (reference constants).  device < 0 selects the current HIP device. */
+ekf_status ekf_create(int n, const ekf_params* params, int device, ekf_handle* out);
+ekf_status ekf_destroy(ekf_handle h);
+/* Copy construction / copy assignment of the by-value member (nuslam/src/slam.cpp:213,428). */
+ekf_status ekf_clone(ekf_handle h, ekf_handle* out);
+
+/* void prediction(const Twist2D&)                   ekf_slam.hpp:31, ekf_slam.cpp:55-106.
+ * dtheta = twist.angular(), dx = twist.linearX(); linearY is ignored by the reference (:70). */
+ekf_status ekf_predict(ekf_handle h, double dtheta, double dx);
+
+/* void measurement(mat sensor_reading, vector<bool> visible_list, vector<bool> known_list)
+ *                                                   ekf_slam.hpp:36, ekf_slam.cpp:108-197.
+ * sensor_xy: 2n doubles (robot-frame x,y per landmark = sensor_reading.memptr());
+ * visible: n bytes.  known_list is unused by the reference and therefore not passed. */
+ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_t* visible);
+
+/* void data_association(vector<Vector2D> measures, vector<bool>& known_list)
+ *                                                   ekf_slam.hpp:41, ekf_slam.cpp:278-402.
+ * meas_xy: 2J doubles (Vector2D is {double x, y}, rigid2d.hpp:68-72, so &measures[0].x);
+ * known: n bytes, IN/OUT (entries are set as landmarks are initialised, :323);
+ * assoc_out: optional J ints, the landmark each measurement updated (-1 = dropped). */
+ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* known, int* assoc_out);
+
+/* double calculate_maha_dis(Vector2D, int) for i in [0, M)   ekf_slam.hpp:86, ekf_slam.cpp:217-276.
+ * Private in the reference; exposed as the parity hook of the one-landmark-per-wavefront
+ * scoring kernel.  scores_out: M doubles. */
+ekf_status ekf_maha_scores(ekf_handle h, double meas_x, double meas_y, int M, double* scores_out);
+
+/* getStateTheta / getStateX / getStateY             ekf_slam.cpp:404-414 -> out = {theta, x, y} */
+ekf_status ekf_get_pose(ekf_handle h, double out[3]);
+/* mat getStateLandmark()                            ekf_slam.cpp:416-418 -> 2n doubles */
+ekf_status ekf_get_landmarks(ekf_handle h, double* out);
+
+/* snapshot / restore and test access to the private members state, sigma (ekf_slam.hpp:61-65) */
+ekf_status ekf_dim(ekf_handle h, int* n, int* N);
+ekf_status ekf_get_state(ekf_handle h, double* out /* N */);
+ekf_status ekf_set_state(ekf_handle h, const double* in /* N */);
+ekf_status ekf_get_cov(ekf_handle h, double* out /* N*N row-major */);
+ekf_status ekf_set_cov(ekf_handle h, const double* in /* N*N row-major */);
+ekf_status ekf_get_init_flag(ekf_handle h, int* flag);  /* landmark_init_flag, ekf_slam.hpp:65 */
+ekf_status ekf_set_init_flag(ekf_handle h, int flag);
+/* Blocks until every kernel queued on the handle's stream has finished. */
+ekf_status ekf_sync(ekf_handle h);
+
+/* ---- batch of independent filters (BASELINE.json configs[4]) -------
+ * Each filter is exactly one EKF_SLAM object; they share nothing.  Inputs are a compact
+ * known-association log (visible readings only, ascending landmark index -- the order of the
+ * loop at ekf_slam.cpp:132), uploaded once so the timed region starts with inputs in HBM. */
+
+typedef struct {
+    int T;               /* steps; step t = prediction(twist[t]) + measurement(readings[t])   */
+    int vmax;            /* reading slots per step                                             */
+    const double* twist; /* [T][B][2]  (dtheta, dx)                                            */
+    const int* lm_idx;   /* [T][B][vmax] landmark index per slot, ascending, -1 ends the list  */
+    const double* z_xy;  /* [T][B][vmax][2] robot-frame (x, y) readings                        */
+    const double* init_xy; /* [B][2n] sensor_reading of the FIRST measurement() call (:113-128) */
+} ekf_known_log;
+
+typedef struct {
+    double elapsed_ms;        /* HIP-event time of the whole run on the batch's stream         */
+    double rank2_ms;          /* sum of the covariance rank-2 kernel's launch durations        */
+    long long rank2_launches; /* launches of that kernel in the run                            */
+    long long corrections;    /* landmark corrections applied over all filters                 */
+    long long filter_steps;   /* (prediction + measurement) pairs over all filters             */
+    double rank2_bytes_per_launch; /* algorithmic bytes: B_active * 2 * 8 * N^2 (average)      */
+} ekf_run_stats;
+
+ekf_status ekf_batch_create(int B, int n, const ekf_params* params, int device, ekf_batch_handle* out);
+ekf_status ekf_batch_destroy(ekf_batch_handle hb);
+/* Re-initialise every filter to the constructor state (ekf_slam.cpp:27-53). */
+ekf_status ekf_batch_reset(ekf_batch_handle hb);
+/* Device bytes the batch holds (covariance pool + state + scratch + uploaded log). */
+ekf_status ekf_batch_device_bytes(ekf_batch_handle hb, size_t* bytes);
+ekf_status ekf_batch_upload_known_log(ekf_batch_handle hb, const ekf_known_log* log);
+/* Runs steps [t_begin, t_end) of the uploaded log for all filters on the batch's stream and
+ * waits for completion.  time_kernels != 0 brackets every rank-2 launch with HIP events. */
+ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int time_kernels,
+                               ekf_run_stats* stats);
+ekf_status ekf_batch_get_state(ekf_batch_handle hb, int b, double* out /* N */);
+ekf_status ekf_batch_get_cov(ekf_batch_handle hb, int b, double* out /* N*N row-major */);
+/* All poses at once: out = [B][3] (theta, x, y) -- the Monte-Carlo read-back. */
+ekf_status ekf_batch_get_poses(ekf_batch_handle hb, double* out);
+/* order-independent digest of every filter's state and covariance (device-side reduction):
+ * out[0] = sum state, out[1] = sum |state|, out[2] = sum sigma, out[3] = sum |sigma| */
+ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]);
+
+/* Tuning knobs of the covariance rank-2 kernel (rows per workgroup, non-temporal access);
+ * <= 0 / < 0 restore the automatic choice.  Results do not depend on them. */
+ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal);
+ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EKFSLAM_H */
