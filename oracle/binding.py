@@ -79,10 +79,12 @@ DENSE, STRUCTURED = 0, 1
 class OracleEKF:
     """Mirror of rigid2d::EKF_SLAM (ekf_slam.hpp:19-57) over the C restatement."""
 
-    def __init__(self, n, mode=DENSE, fast=False):
+    def __init__(self, n, mode=DENSE, fast=False, params=None):
+        """params: optional 6-tuple (sigma0_landmark, q_pose, r_meas, gate_new, gate_update, straight_eps)."""
         self._lib = lib(fast)
         self.n, self.N, self.mode = n, 3 + 2 * n, mode
-        self._h = self._lib.ekfo_create(n, mode, None)
+        pp = (C.c_double * 6)(*[float(x) for x in params]) if params is not None else None
+        self._h = self._lib.ekfo_create(n, mode, pp)
         if not self._h:
             raise MemoryError("ekfo_create failed")
 

@@ -1,0 +1,96 @@
+"""Generates the committed golden vectors under tests/golden/ (run from the repo root:
+`python tests/golden/make_golden.py`).
+
+PARITY UNPINNED: the reference (rigid2d/src/ekf_slam.cpp) cannot be built in this image -- it needs
+Armadillo -- and its own tests hold no EKF_SLAM vectors, so these fixtures are produced by the two
+independent CPU restatements under oracle/ (dense-literal C and NumPy), which must agree to 1e-12 per
+block before anything is written.  Inputs come from ekf_slam_ml_amd/synth.py (deterministic) and are
+stored next to the expected outputs so the fixtures stay valid even if the generator changes."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+from ekf_slam_ml_amd import synth  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+from oracle.np_restatement import NumpyEKF  # noqa: E402
+from parity import worst  # noqa: E402
+
+AGREE = 1e-12
+
+
+def agree(o, p, what):
+    w, e = worst(o.state, o.cov, p.state, p.sigma)
+    assert w <= AGREE, f"{what}: C and NumPy restatements disagree: {e}"
+    return w
+
+
+def known(name, cfg, checkpoints):
+    log = synth.make_known_log(cfg)
+    n, T = cfg.n, cfg.steps
+    o, p = ob.OracleEKF(n, ob.DENSE), NumpyEKF(n)
+    cp_state = []
+    for t in range(T):
+        sensor, vis = log.expand_step(t)
+        for f in (o, p):
+            f.prediction(*log.twist[t, 0])
+            f.measurement(sensor, vis)
+        if t in checkpoints:
+            cp_state.append(o.state.copy())
+    w = agree(o, p, name)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), n=n, twist=log.twist[:, 0], lm_idx=log.lm_idx[:, 0],
+                        z_xy=log.z_xy[:, 0], init_xy=log.init_xy[0], checkpoints=np.array(sorted(checkpoints)),
+                        cp_state=np.array(cp_state), state=o.state, cov=o.cov)
+    print(f"{name}: n={n} T={T} corrections={log.corrections} C-vs-NumPy {w:.2e}")
+
+
+def unknown(name, cfg):
+    log = synth.make_unknown_log(cfg)
+    n, T = cfg.n, cfg.steps
+    o, p = ob.OracleEKF(n, ob.DENSE), NumpyEKF(n)
+    ko, kp = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    assoc = np.full((T, log.meas_xy.shape[2]), -2, dtype=np.int32)
+    for t in range(T):
+        J = int(log.count[t, 0])
+        m = log.meas_xy[t, 0, :J]
+        o.prediction(*log.twist[t, 0]); p.prediction(*log.twist[t, 0])
+        a = o.data_association(m, ko)
+        b = p.data_association(m, kp)
+        assert np.array_equal(a, b) and np.array_equal(ko, kp), f"{name}: decisions differ at step {t}"
+        assoc[t, :J] = a
+    w = agree(o, p, name)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), n=n, twist=log.twist[:, 0], count=log.count[:, 0],
+                        meas_xy=log.meas_xy[:, 0], assoc=assoc, known=ko, state=o.state, cov=o.cov)
+    print(f"{name}: n={n} T={T} known={int(ko.sum())} updates={(assoc >= 0).sum()} dropped={(assoc == -1).sum()} "
+          f"C-vs-NumPy {w:.2e}")
+
+
+def maha(name):
+    """calculate_maha_dis vectors on a mid-run snapshot (state, cov) of the known-association run."""
+    g = np.load(os.path.join(HERE, "known_n20.npz"))
+    n = int(g["n"])
+    o, p = ob.OracleEKF(n, ob.DENSE), NumpyEKF(n)
+    o.state, o.cov = g["state"], g["cov"]
+    o.set_init_flag(1)
+    p.state, p.sigma, p.landmark_init_flag = g["state"].copy(), g["cov"].copy(), True
+    meas = np.array([[0.31, -0.12], [-0.4, 0.55], [0.05, 0.02], [1.2, -0.9]])
+    scores = np.array([[o.maha(mx, my, i) for i in range(n)] for mx, my in meas])
+    scores_np = np.array([[p.maha(mx, my, i) for i in range(n)] for mx, my in meas])
+    assert np.abs(scores - scores_np).max() / np.abs(scores).max() < 1e-11
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), n=n, state=g["state"], cov=g["cov"], meas=meas, scores=scores)
+    print(f"{name}: {scores.shape} scores, range [{scores.min():.3g}, {scores.max():.3g}]")
+
+
+if __name__ == "__main__":
+    ob.build()
+    known("known_n20", synth.config1(steps=250), {0, 1, 10, 100, 249})
+    c = synth.config1(steps=200)
+    c.seed = 77
+    unknown("unknown_n20", c)
+    c2 = synth.config2(steps=12)
+    known("known_n200", c2, {0, 5, 11})
+    maha("maha_n20")
