@@ -141,14 +141,15 @@ def main():
                        "hbm_bytes_per_gpu": bt.device_bytes()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ekf::k_rank2<256,4,NT> (Sigma -= K*(H*Sigma))",
+                         "kernel": "ekf::k_rank2<16,true> (Sigma -= K*(H*Sigma), ekf_slam.cpp:191-192)",
                          "algorithmic_bytes_per_launch": st["rank2_bytes_per_launch"],
                          "avg_launch_ms": r2_avg_s * 1e3, "launches": st["rank2_launches"],
                          "rank2_share_of_step_time": st["rank2_ms"] / st["elapsed_ms"]},
             "device_elapsed_ms": st["elapsed_ms"],
         }
         if world == 1 and not a.no_cpu_baseline:
-            cores = os.cpu_count() or 1
+            # the box's CPU share for a one-GPU job is 16 cores (the machine reports all 256)
+            cores = int(os.environ.get("EKF_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
             Bc = a.cpu_filters if a.cpu_filters > 0 else min(B, 4 * cores)
             import copy
             cfg_c = copy.copy(cfg)

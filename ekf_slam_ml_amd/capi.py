@@ -98,7 +98,7 @@ def load():
         "ekf_get_init_flag": [h, _ip],
         "ekf_set_init_flag": [h, C.c_int],
         "ekf_sync": [h],
-        "ekf_set_tuning": [h, C.c_int, C.c_int],
+        "ekf_set_tuning": [h, C.c_int, C.c_int, C.c_int],
         "ekf_batch_create": [C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.POINTER(h)],
         "ekf_batch_destroy": [h],
         "ekf_batch_reset": [h],
@@ -109,7 +109,7 @@ def load():
         "ekf_batch_get_cov": [h, C.c_int, _dp],
         "ekf_batch_get_poses": [h, _dp],
         "ekf_batch_checksum": [h, _dp],
-        "ekf_batch_set_tuning": [h, C.c_int, C.c_int],
+        "ekf_batch_set_tuning": [h, C.c_int, C.c_int, C.c_int],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -253,8 +253,8 @@ class EKF_SLAM:
     def sync(self):
         _check(self._lib.ekf_sync(self._h))
 
-    def set_tuning(self, rows_per_block=0, nontemporal=-1):
-        _check(self._lib.ekf_set_tuning(self._h, rows_per_block, nontemporal))
+    def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
+        _check(self._lib.ekf_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
 
 
 class BatchEKF:
@@ -323,5 +323,5 @@ class BatchEKF:
         _check(self._lib.ekf_batch_checksum(self._h, _d(out)))
         return out
 
-    def set_tuning(self, rows_per_block=0, nontemporal=-1):
-        _check(self._lib.ekf_batch_set_tuning(self._h, rows_per_block, nontemporal))
+    def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
+        _check(self._lib.ekf_batch_set_tuning(self._h, rows_per_block, nontemporal, group_rows))

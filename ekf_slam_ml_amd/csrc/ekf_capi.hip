@@ -72,7 +72,7 @@ struct Pool {
     int device = -1;
     hipStream_t stream = nullptr;
     ekf::PoolView pv{};
-    ekf::Rank2Tuning tuning{0, -1};
+    ekf::Rank2Tuning tuning{0, -1, 0};
     size_t dev_bytes = 0;
     int init_flag = 0;  // landmark_init_flag, ekf_slam.hpp:65
 
@@ -452,9 +452,9 @@ ekf_status ekf_sync(ekf_handle h) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     return h->pool.sync();
 }
-ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal) {
+ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal, int group_rows) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
-    h->pool.tuning = ekf::Rank2Tuning{rows_per_block, nontemporal};
+    h->pool.tuning = ekf::Rank2Tuning{rows_per_block, nontemporal, group_rows};
     return EKF_OK;
 }
 
@@ -494,9 +494,9 @@ ekf_status ekf_batch_device_bytes(ekf_batch_handle hb, size_t* bytes) {
     return EKF_OK;
 }
 
-ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal) {
+ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal, int group_rows) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
-    hb->pool.tuning = ekf::Rank2Tuning{rows_per_block, nontemporal};
+    hb->pool.tuning = ekf::Rank2Tuning{rows_per_block, nontemporal, group_rows};
     return EKF_OK;
 }
 

@@ -236,10 +236,9 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
         k0 = sht0 * sh_Si[0] + sht1 * sh_Si[2];  // K = (Sigma H^T) S^-1   :178
         k1 = sht0 * sh_Si[1] + sht1 * sh_Si[3];
     }
-    double* Kg = pv.Kg + (size_t)b * 2 * ld;
+    double2_t* Kg = reinterpret_cast<double2_t*>(pv.Kg + (size_t)b * 2 * ld);
     double* Gh = pv.Gh + (size_t)b * 2 * ld;
-    Kg[r] = k0;
-    Kg[ld + r] = k1;
+    Kg[r] = double2_t{k0, k1};
     Gh[r] = g0;
     Gh[ld + r] = g1;
 }
@@ -249,11 +248,16 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
 // (ekf_slam.cpp:191-192) evaluated as Sigma[r][c] -= K[r][0]*G[0][c] + K[r][1]*G[1][c].
 // Algorithmic traffic 2*8*N^2 bytes (read + write Sigma once), 4 N^2 flop -> HBM-bound.
 //
-// Workgroup = 256 threads as TX column lanes x TY = 256/TX row lanes.  A thread owns CH double2
-// columns (stride TX) whose G values live in registers for the whole row loop, and streams
-// rows_per_block rows with 16-B loads/stores (every wave instruction moves 1 KiB contiguous when
-// TX >= 64).  K[r][*] is uniform per row.  The same workgroups apply state += K*nu (:186) and the
-// theta wrap (:187).  grid (col blocks, row blocks, B).
+// A workgroup owns a strip of 256 double2 columns (4 KiB per row; every wave instruction moves
+// 1 KiB contiguous) and rows_per_block rows.  A lane keeps its two G values in registers and streams
+// its column down the rows in groups of U rows through a ring of three register buffers: the U loads
+// of group g+1 are issued BEFORE the U stores of group g, so in the in-order vmcnt queue a load is
+// older than the stores around it and waiting for it does not drain them.  The main loop has no branch
+// (the lane-validity test wraps it), which keeps hipcc's s_waitcnt counts exact.  K(r,:) is
+// wave-uniform and arrives through the scalar cache (lgkmcnt), off the vector-memory queue.
+// Sigma, K, G, rec and state never alias (__restrict__), so those scalar loads stay legal after the
+// first Sigma store.  The same workgroups apply state += K*nu (:186) and the theta wrap (:187).
+// grid (ceil(ld2n/256), row blocks, B).
 // ---------------------------------------------------------------------------------------------
 template <bool NT>
 __device__ __forceinline__ double2_t ld2(const double2_t* p) {
@@ -266,83 +270,89 @@ __device__ __forceinline__ void st2(double2_t* p, double2_t v) {
     else *p = v;
 }
 
-template <int TX, int CH, bool NT>
-__global__ __launch_bounds__(256) void k_rank2(PoolView pv, int rows_per_block) {
-    constexpr int TY = 256 / TX;
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_rank2(double* __restrict__ sigma, const double* __restrict__ Kg_all,
+                                               const double* __restrict__ Gh_all, const CorrRec* __restrict__ rec,
+                                               double* __restrict__ state, int N, int ld, size_t sigma_stride,
+                                               int rows_per_block) {
     const int b = blockIdx.z;
-    if (!pv.rec[b].active) return;
-    const int N = pv.N, ld = pv.ld, ld2n = ld >> 1;
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int cbase = blockIdx.x * (TX * CH) + tx;
-    const double* Kg = pv.Kg + (size_t)b * 2 * ld;
-    const double2_t* G0 = reinterpret_cast<const double2_t*>(pv.Gh + (size_t)b * 2 * ld);
-    const double2_t* G1 = reinterpret_cast<const double2_t*>(pv.Gh + (size_t)b * 2 * ld + ld);
-    double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
-
-    double2_t g0[CH], g1[CH];
-    bool ok[CH];
-#pragma unroll
-    for (int ch = 0; ch < CH; ch++) {
-        const int c2 = cbase + ch * TX;
-        ok[ch] = c2 < ld2n;
-        g0[ch] = ok[ch] ? G0[c2] : double2_t{0.0, 0.0};
-        g1[ch] = ok[ch] ? G1[c2] : double2_t{0.0, 0.0};
-    }
-
+    if (!rec[b].active) return;
+    const int ld2n = ld >> 1;
+    const int c2 = blockIdx.x * 256 + threadIdx.x;
+    const double2_t* __restrict__ Kg = reinterpret_cast<const double2_t*>(Kg_all + (size_t)b * 2 * ld);
     const int row_begin = blockIdx.y * rows_per_block;
     const int row_end = min(N, row_begin + rows_per_block);
-    int r = row_begin + ty;
-    // two rows per trip: 2*CH independent 16-B loads in flight per lane before the first use
-    for (; r + TY < row_end; r += 2 * TY) {
-        const int ra = r, rb = r + TY;
-        const double ka0 = Kg[ra], ka1 = Kg[ld + ra];
-        const double kb0 = Kg[rb], kb1 = Kg[ld + rb];
-        double2_t* rowa = reinterpret_cast<double2_t*>(Sg + (size_t)ra * ld);
-        double2_t* rowb = reinterpret_cast<double2_t*>(Sg + (size_t)rb * ld);
-        double2_t va[CH], vb[CH];
+
+    if (c2 < ld2n) {
+        const double2_t g0 = reinterpret_cast<const double2_t*>(Gh_all + (size_t)b * 2 * ld)[c2];
+        const double2_t g1 = reinterpret_cast<const double2_t*>(Gh_all + (size_t)b * 2 * ld + ld)[c2];
+        double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + c2;
+
+        auto load_group = [&](double2_t (&buf)[U], int row) {
 #pragma unroll
-        for (int ch = 0; ch < CH; ch++)
-            if (ok[ch]) va[ch] = ld2<NT>(rowa + cbase + ch * TX);
+            for (int u = 0; u < U; u++) buf[u] = ld2<NT>(col + (size_t)(row + u) * ld2n);
+        };
+        auto finish_group = [&](double2_t (&buf)[U], int row) {
 #pragma unroll
-        for (int ch = 0; ch < CH; ch++)
-            if (ok[ch]) vb[ch] = ld2<NT>(rowb + cbase + ch * TX);
-#pragma unroll
-        for (int ch = 0; ch < CH; ch++)
-            if (ok[ch]) {
-                va[ch].x = va[ch].x - (ka0 * g0[ch].x + ka1 * g1[ch].x);
-                va[ch].y = va[ch].y - (ka0 * g0[ch].y + ka1 * g1[ch].y);
-                st2<NT>(rowa + cbase + ch * TX, va[ch]);
+            for (int u = 0; u < U; u++) {
+                const double2_t k = Kg[row + u];  // uniform address -> s_load
+                double2_t v = buf[u];
+                v.x = v.x - (k.x * g0.x + k.y * g1.x);
+                v.y = v.y - (k.x * g0.y + k.y * g1.y);
+                st2<NT>(col + (size_t)(row + u) * ld2n, v);
             }
-#pragma unroll
-        for (int ch = 0; ch < CH; ch++)
-            if (ok[ch]) {
-                vb[ch].x = vb[ch].x - (kb0 * g0[ch].x + kb1 * g1[ch].x);
-                vb[ch].y = vb[ch].y - (kb0 * g0[ch].y + kb1 * g1[ch].y);
-                st2<NT>(rowb + cbase + ch * TX, vb[ch]);
+        };
+
+        const int nfull = (row_end - row_begin) / U;  // uniform
+        int r = row_begin;
+        if (nfull > 0) {
+            // Three register buffers: hipcc orders a reload of a buffer behind the completion of the
+            // stores that read it (vmcnt), so the buffer reloaded in a sub-step must be the one stored
+            // TWO sub-steps ago -- then U loads + U stores stay in flight across every wait.
+            double2_t A[U], Bf[U], Cf[U];
+            load_group(A, r);
+            int g = 0;
+            for (; g + 3 < nfull; g += 3) {  // invariant: A holds group g; no branch inside
+                load_group(Bf, r + U);
+                finish_group(A, r);
+                load_group(Cf, r + 2 * U);
+                finish_group(Bf, r + U);
+                load_group(A, r + 3 * U);
+                finish_group(Cf, r + 2 * U);
+                r += 3 * U;
             }
-    }
-    for (; r < row_end; r += TY) {
-        const double k0 = Kg[r], k1 = Kg[ld + r];
-        double2_t* row = reinterpret_cast<double2_t*>(Sg + (size_t)r * ld);
-        double2_t v[CH];
-#pragma unroll
-        for (int ch = 0; ch < CH; ch++)
-            if (ok[ch]) v[ch] = ld2<NT>(row + cbase + ch * TX);
-#pragma unroll
-        for (int ch = 0; ch < CH; ch++)
-            if (ok[ch]) {
-                v[ch].x = v[ch].x - (k0 * g0[ch].x + k1 * g1[ch].x);
-                v[ch].y = v[ch].y - (k0 * g0[ch].y + k1 * g1[ch].y);
-                st2<NT>(row + cbase + ch * TX, v[ch]);
+            const int rem = nfull - g;  // 1, 2 or 3 groups left, A already loaded
+            if (rem == 1) {
+                finish_group(A, r);
+            } else if (rem == 2) {
+                load_group(Bf, r + U);
+                finish_group(A, r);
+                finish_group(Bf, r + U);
+            } else {
+                load_group(Bf, r + U);
+                finish_group(A, r);
+                load_group(Cf, r + 2 * U);
+                finish_group(Bf, r + U);
+                finish_group(Cf, r + 2 * U);
             }
+            r += rem * U;
+        }
+        for (; r < row_end; r++) {  // < U leftover rows of the last row block
+            const double2_t k = Kg[r];
+            double2_t v = ld2<NT>(col + (size_t)r * ld2n);
+            v.x = v.x - (k.x * g0.x + k.y * g1.x);
+            v.y = v.y - (k.x * g0.y + k.y * g1.y);
+            st2<NT>(col + (size_t)r * ld2n, v);
+        }
     }
 
     // state = state + Ki*z_diff (:186); state(0) = normalize_angle(state(0)) (:187)
     if (blockIdx.x == 0) {
-        const CorrRec rc = pv.rec[b];
-        double* st = pv.state + (size_t)b * ld;
+        const CorrRec rc = rec[b];
+        double* st = state + (size_t)b * ld;
         for (int rr = row_begin + (int)threadIdx.x; rr < row_end; rr += 256) {
-            double s = st[rr] + (Kg[rr] * rc.nu0 + Kg[ld + rr] * rc.nu1);
+            const double2_t k = Kg[rr];
+            double s = st[rr] + (k.x * rc.nu0 + k.y * rc.nu1);
             if (rr == 0) s = normalize_angle(s);
             st[rr] = s;
         }
@@ -525,38 +535,41 @@ void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s) {
     hipLaunchKernelGGL(k_gain, dim3((pv.ld + 255) / 256, pv.B), dim3(256), 0, s, pv, src);
 }
 
-template <int TX, int CH>
-static void launch_rank2_t(const PoolView& pv, int rows, bool nt, hipStream_t s) {
+template <int U>
+static void launch_rank2_u(const PoolView& pv, int rows, bool nt, hipStream_t s) {
     const int ld2n = pv.ld / 2;
-    dim3 grid((ld2n + TX * CH - 1) / (TX * CH), (pv.N + rows - 1) / rows, pv.B);
-    if (nt) hipLaunchKernelGGL((k_rank2<TX, CH, true>), grid, dim3(256), 0, s, pv, rows);
-    else hipLaunchKernelGGL((k_rank2<TX, CH, false>), grid, dim3(256), 0, s, pv, rows);
+    dim3 grid((ld2n + 255) / 256, (pv.N + rows - 1) / rows, pv.B);
+    if (nt)
+        hipLaunchKernelGGL((k_rank2<U, true>), grid, dim3(256), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
+                           pv.N, pv.ld, pv.sigma_stride, rows);
+    else
+        hipLaunchKernelGGL((k_rank2<U, false>), grid, dim3(256), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
+                           pv.N, pv.ld, pv.sigma_stride, rows);
 }
 
 void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s) {
-    const int ld2n = pv.ld / 2;
     // Non-temporal only when the pool cannot stay resident in the 256 MiB Infinity Cache between
     // two corrections; a single filter's covariance (32 MB at n = 1000) should stay cached.
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
+    int u = t.group_rows;
     int rows = t.rows_per_block;
-    const int ty = ld2n <= 256 ? 4 : 1;  // TX = 64 -> 4 row lanes
     if (rows <= 0) {
-        // enough workgroups to fill 256 CUs several times over, but rows long enough to amortise
-        // the per-workgroup G fetch
-        const long long total_rows = (long long)pv.B * pv.N;
-        rows = total_rows >= 256LL * 8 * 16 ? 16 : (total_rows >= 256LL * 8 * 4 ? 4 : 2);
-        rows *= ty;
+        // Measured on MI355X (profiles/): a big pool streams fastest with 32 rows per workgroup taken as
+        // two 16-row groups (32 x 16 B in flight per lane, 2 waves/SIMD): 6.17 TB/s algorithmic.  A small
+        // pool needs enough workgroups to cover 256 CUs a few times over.
+        const long long strips = (long long)pv.B * ((pv.ld / 2 + 255) / 256);
+        const long long total = strips * pv.N;
+        rows = total >= 256LL * 8 * 32 ? 32 : (total >= 256LL * 4 * 8 ? 8 : 4);
     }
-    if (rows > 256) rows = 256;
-    if (rows < ty) rows = ty;
-    if (ld2n <= 64) launch_rank2_t<64, 1>(pv, rows, nt, s);
-    else if (ld2n <= 128) launch_rank2_t<64, 2>(pv, rows, nt, s);
-    else if (ld2n <= 192) launch_rank2_t<64, 3>(pv, rows, nt, s);
-    else if (ld2n <= 256) launch_rank2_t<64, 4>(pv, rows, nt, s);
-    else if (ld2n <= 512) launch_rank2_t<256, 2>(pv, rows, nt, s);
-    else if (ld2n <= 768) launch_rank2_t<256, 3>(pv, rows, nt, s);
-    else launch_rank2_t<256, 4>(pv, rows, nt, s);
+    if (rows > 1024) rows = 1024;
+    if (u != 2 && u != 4 && u != 8 && u != 16) u = rows >= 32 ? 16 : (rows >= 8 ? 8 : (rows >= 4 ? 4 : 2));
+    switch (u) {
+        case 2: launch_rank2_u<2>(pv, rows, nt, s); break;
+        case 4: launch_rank2_u<4>(pv, rows, nt, s); break;
+        case 16: launch_rank2_u<16>(pv, rows, nt, s); break;
+        default: launch_rank2_u<8>(pv, rows, nt, s); break;
+    }
 }
 
 void launch_maha(const PoolView& pv, const double* meas, double* scores, int m_override, hipStream_t s) {

@@ -5,7 +5,7 @@
 //   sigma  [N][ld]   fp64 row-major, ld = N rounded up to 16 doubles (rows start on 128-B lines,
 //                    so every lane moves aligned 16-B double2); pad columns stay 0
 //   state  [ld]      [theta, x, y, m1x, m1y, ...]                  (ekf_slam.cpp:15-21,72-74)
-//   Kg     [2][ld]   Kalman gain columns K(:,0), K(:,1)  (scratch between gain and rank-2 kernel)
+//   Kg     [ld][2]   Kalman gain rows (K(r,0), K(r,1))   (scratch between gain and rank-2 kernel)
 //   Gh     [2][ld]   rows of H*Sigma                      (pad entries 0)
 //   rec              per-filter correction record (innovation, active flag)
 //   snap   [4]       pose captured at the top of measurement()      (ekf_slam.cpp:109-111)
@@ -134,6 +134,7 @@ __device__ __forceinline__ void inv2(const double S[2][2], double Si[2][2]) {
 struct Rank2Tuning {
     int rows_per_block;  // <= 0: automatic
     int nontemporal;     // < 0: automatic
+    int group_rows;      // rows per load/store group U in {2,4,8}; other values: automatic
 };
 
 void launch_init(const PoolView& pv, hipStream_t s);

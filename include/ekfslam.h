@@ -145,10 +145,11 @@ ekf_status ekf_batch_get_poses(ekf_batch_handle hb, double* out);
  * out[0] = sum state, out[1] = sum |state|, out[2] = sum sigma, out[3] = sum |sigma| */
 ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]);
 
-/* Tuning knobs of the covariance rank-2 kernel (rows per workgroup, non-temporal access);
- * <= 0 / < 0 restore the automatic choice.  Results do not depend on them. */
-ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal);
-ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal);
+/* Tuning knobs of the covariance rank-2 kernel: rows per workgroup, non-temporal access (0/1),
+ * rows per load/store group (2, 4 or 8).  <= 0 (nontemporal: < 0) restores the automatic choice.
+ * Results do not depend on them, bit for bit. */
+ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal, int group_rows);
+ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal, int group_rows);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,75 @@
+"""Condenses a tools/profile_bench.sh output directory into the numbers the bench line quotes:
+per-kernel time stats (rocprofv3 --kernel-trace --stats) and HBM bytes per launch of the rank-2 kernel
+from the FETCH_SIZE / WRITE_SIZE passes, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes
+(gfx950: FETCH_SIZE counts half the bytes of a wide coalesced stream -> x2; both counters are in KiB)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out = sys.argv[1]
+
+
+def find(sub, pat):
+    hits = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    return hits[0] if hits else None
+
+
+def bench_line(name):
+    try:
+        with open(os.path.join(out, name)) as f:
+            for line in f:
+                if line.startswith("{"):
+                    return json.loads(line)
+    except OSError:
+        pass
+    return None
+
+
+summary = {}
+stats = find("trace", "*kernel_stats.csv")
+print("== rocprofv3 --kernel-trace --stats (per kernel) ==")
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    for r in rows:
+        print(f"{r['Name'][:90]:90s} calls {r['Calls']:>6s} total_ms {float(r['TotalDurationNs']) / 1e6:10.3f} "
+              f"avg_us {float(r['AverageNs']) / 1e3:12.2f} pct {r['Percentage']}")
+        if "k_rank2" in r["Name"]:
+            summary["rank2_avg_ms_rocprof"] = float(r["AverageNs"]) / 1e6
+            summary["rank2_calls"] = int(r["Calls"])
+b = bench_line("bench_trace.json")
+if b:
+    summary["bench_under_trace"] = {"value": b["value"], "roofline": b["roofline"]}
+    print("bench.py (same run): avg rank-2 launch", b["roofline"]["avg_launch_ms"], "ms (HIP events);",
+          "rocprof:", summary.get("rank2_avg_ms_rocprof"))
+
+
+def counter(sub, cname):
+    f = find(sub, "*counter_collection.csv")
+    if not f:
+        return None
+    tot, cnt = 0.0, 0
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") == cname and "k_rank2" in r.get("Kernel_Name", ""):
+            tot += float(r["Counter_Value"])
+            cnt += 1
+    return (tot / cnt, cnt) if cnt else None
+
+
+fs = counter("pmc_fetch", "FETCH_SIZE")
+ws = counter("pmc_write", "WRITE_SIZE")
+print("== PMC (per rank-2 launch) ==")
+if fs and ws:
+    fetch_bytes = fs[0] * 1024.0 * 2.0  # gfx950 correction: x2 on wide coalesced reads
+    write_bytes = ws[0] * 1024.0
+    alg = b["roofline"]["algorithmic_bytes_per_launch"] if b else None
+    print(f"FETCH_SIZE avg {fs[0]:.0f} KiB over {fs[1]} launches -> {fetch_bytes / 1e9:.2f} GB after x2 correction")
+    print(f"WRITE_SIZE avg {ws[0]:.0f} KiB over {ws[1]} launches -> {write_bytes / 1e9:.2f} GB")
+    print(f"HBM traffic per launch {(fetch_bytes + write_bytes) / 1e9:.2f} GB vs algorithmic {alg / 1e9 if alg else float('nan'):.2f} GB")
+    summary.update({"fetch_size_kib": fs[0], "write_size_kib": ws[0], "hbm_bytes_per_launch": fetch_bytes + write_bytes,
+                    "algorithmic_bytes_per_launch": alg})
+    if b:
+        summary["filters"] = b["config"]["filters_per_gpu"]
+        summary["n"] = b["config"]["landmarks"]
+json.dump(summary, open(os.path.join(out, "rank2_traffic.json"), "w"), indent=1)
