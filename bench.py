@@ -83,7 +83,10 @@ def main():
     K, W = a.steps, a.warmup
     T = W + K + 1  # step 0 = first measurement() call (landmark initialisation, no corrections)
 
-    cfg = synth.config5(filters=B, steps=T, first_filter_id=rank * B, n=n)
+    from ekf_slam_ml_amd import shard
+    first_id, count = shard.shard(B * world, world, rank)  # weak scaling: B filters per GPU, global ids
+    assert count == B
+    cfg = synth.config5(filters=B, steps=T, first_filter_id=first_id, n=n)
     log = synth.make_known_log(cfg)
     bt = capi.BatchEKF(B, n, device=local)
     bt.set_tuning(a.rows, a.nt)
@@ -106,13 +109,8 @@ def main():
 
     corr = float(st["corrections"])
     fsteps = float(st["filter_steps"])
-    if dist is not None:
-        tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        sums = torch.tensor([corr, fsteps], dtype=torch.float64, device="cuda")
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        wall = float(tmax.item())
-        corr, fsteps = float(sums[0].item()), float(sums[1].item())
+    # the only collective of the job: RCCL all-reduce of three scalars (max wall, summed work)
+    wall, corr, fsteps = shard.reduce_throughput(wall, corr, fsteps, device="cuda")
 
     if rank == 0:
         r2_avg_s = st["rank2_ms"] / max(st["rank2_launches"], 1) * 1e-3

@@ -156,6 +156,7 @@ class KnownLog:
     z_xy: np.ndarray
     init_xy: np.ndarray
     true_pose: np.ndarray = field(repr=False, default=None)
+    wheel: np.ndarray = field(repr=False, default=None)  # [T,B,2] last 100 Hz wheel deltas (joint_states velocity)
 
     @property
     def corrections(self):
@@ -189,6 +190,7 @@ class UnknownLog:
     meas_xy: np.ndarray    # [T,B,jmax,2]
     truth_idx: np.ndarray  # [T,B,jmax] int32 generating landmark (diagnostics only)
     true_pose: np.ndarray = field(repr=False, default=None)
+    wheel: np.ndarray = field(repr=False, default=None)  # [T,B,2] last 100 Hz wheel deltas
 
 
 def _simulate(cfg: SimConfig):
@@ -200,6 +202,7 @@ def _simulate(cfg: SimConfig):
     x = np.zeros(B)
     y = np.zeros(B)
     twist = np.zeros((T, B, 2))
+    wheel = np.zeros((T, B, 2))
     true_pose = np.zeros((T, B, 3))
     for t in range(T):
         # callback_vel: noise only on non-zero commands (tube_world.cpp:191-208)
@@ -218,8 +221,10 @@ def _simulate(cfg: SimConfig):
         tw_a, tw_x = body_twist(dl * 10.0, dr * 10.0)
         twist[t, :, 0] = tw_a
         twist[t, :, 1] = tw_x
+        wheel[t, :, 0] = dl
+        wheel[t, :, 1] = dr
         true_pose[t, :, 0], true_pose[t, :, 1], true_pose[t, :, 2] = theta, x, y
-    return world, twist, true_pose, fid
+    return world, twist, true_pose, fid, wheel
 
 
 def _robot_frame(world, pose):
@@ -233,7 +238,7 @@ def _robot_frame(world, pose):
 
 def make_known_log(cfg: SimConfig) -> KnownLog:
     B, T, n, vmax = cfg.filters, cfg.steps, cfg.n, cfg.vmax
-    world, twist, true_pose, fid = _simulate(cfg)
+    world, twist, true_pose, fid, wheel = _simulate(cfg)
     lm_idx = np.full((T, B, vmax), -1, dtype=np.int32)
     z_xy = np.zeros((T, B, vmax, 2))
     init_xy = np.zeros((B, 2 * n))
@@ -270,14 +275,14 @@ def make_known_log(cfg: SimConfig) -> KnownLog:
             lm_idx[t, :, :k] = np.where(keep, np.take_along_axis(near, order, axis=1), -1)
             z_xy[t, :, :k, 0] = np.where(keep, np.take_along_axis(zx, order, axis=1), 0.0)
             z_xy[t, :, :k, 1] = np.where(keep, np.take_along_axis(zy, order, axis=1), 0.0)
-    return KnownLog(cfg, world, twist, lm_idx, z_xy, init_xy, true_pose)
+    return KnownLog(cfg, world, twist, lm_idx, z_xy, init_xy, true_pose, wheel)
 
 
 def make_unknown_log(cfg: SimConfig) -> UnknownLog:
     """Every step (including step 0) carries up to vmax shuffled readings of the
     landmarks within max_visible_dis; the filter discovers landmarks in that order."""
     B, T, n, jmax = cfg.filters, cfg.steps, cfg.n, cfg.vmax
-    world, twist, true_pose, fid = _simulate(cfg)
+    world, twist, true_pose, fid, wheel = _simulate(cfg)
     count = np.zeros((T, B), dtype=np.int32)
     meas = np.zeros((T, B, jmax, 2))
     truth = np.full((T, B, jmax), -1, dtype=np.int32)
@@ -298,7 +303,7 @@ def make_unknown_log(cfg: SimConfig) -> UnknownLog:
             meas[t, b, :J, 0] = rf[b, vis, 0] + nx
             meas[t, b, :J, 1] = rf[b, vis, 1] + ny
             truth[t, b, :J] = vis
-    return UnknownLog(cfg, world, twist, count, meas, truth, true_pose)
+    return UnknownLog(cfg, world, twist, count, meas, truth, true_pose, wheel)
 
 
 # ---- the BASELINE.json configurations -------------------------------

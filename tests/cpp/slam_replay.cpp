@@ -1,0 +1,137 @@
+// slam_replay.cpp -- ROS-free replay of the nuslam SLAM node loop over the C++ mirror class
+// (ekf_slam_ml_amd/host/ekf_slam.hpp).  It reproduces the CALLER side of the hot path:
+//   Odometer::getCurrentTwist        nuslam/src/slam.cpp:173-176 (+ DiffDrive::getBodyTwistForUpdate,
+//                                    rigid2d/src/diff_drive.cpp:38-47)
+//   SLAM::callback_fake_sensor       nuslam/src/slam.cpp:305-333
+//   SLAM::callback_scan_sensor       nuslam/src/unknown_data_assoc.cpp:309-320
+//   SLAM::main_loop (INIT / UPDATE)  nuslam/src/slam.cpp:419-448, unknown_data_assoc.cpp:402-429
+// Input: a text log written by tests/test_gpu_host_cpp.py; output: state, covariance, known_list.
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../ekf_slam_ml_amd/host/ekf_slam.hpp"
+
+using ekfslam::EKF_SLAM;
+using ekfslam::Twist2D;
+using ekfslam::Vector2D;
+
+// Odometer of slam.cpp:43-188, reduced to what feeds the filter.
+struct Odometer {
+    double wheel_base, wheel_radius;
+    double delta_left = 0.0, delta_right = 0.0;  // joints.velocity[0..1], slam.cpp:157-165
+    Twist2D getCurrentTwist() const {            // slam.cpp:173-176: the 100 Hz deltas x10
+        const double left = delta_left * 10.0, right = delta_right * 10.0;
+        const double D = wheel_base * 0.5, r = wheel_radius;  // diff_drive.cpp:38-47
+        const double ts_angle = (r / (2.0 * D)) * (right - left);
+        const double ts_x = (r / 2.0) * (right + left);
+        return Twist2D(ts_angle, Vector2D{ts_x, 0.0});
+    }
+};
+
+enum class SLAMState { INIT, UPDATE };
+
+struct Marker { int id; double x, y; int add; };
+
+struct SLAM {
+    int max_n_tubes;
+    bool unknown_assoc;
+    Odometer& odometer;
+    SLAMState state_machine = SLAMState::INIT;
+    bool sensor_update_flag = false, state_update_flag = false;
+    std::vector<bool> visible_list, known_list;
+    std::vector<double> sensor_reading;  // zeros<mat>(max_n_tubes*2, 1), slam.cpp:259
+    std::vector<Vector2D> scan_measures;
+    EKF_SLAM slam_agent;                 // by-value member, slam.cpp:213
+
+    SLAM(int n, bool unknown, Odometer& odo)
+        : max_n_tubes(n), unknown_assoc(unknown), odometer(odo), visible_list(n, false), known_list(n, false),
+          sensor_reading(2 * n, 0.0) {}
+
+    void callback_fake_sensor(const std::vector<Marker>& tubes) {  // slam.cpp:305-333
+        for (size_t i = 0; i < tubes.size(); i++) {
+            sensor_reading[i * 2] = tubes[i].x;
+            sensor_reading[i * 2 + 1] = tubes[i].y;
+            if (state_update_flag) {
+                if (tubes[i].add) { visible_list[i] = true; known_list[i] = true; }
+                else visible_list[i] = false;
+            }
+        }
+        sensor_update_flag = true;
+    }
+    void callback_scan_sensor(const std::vector<Marker>& tubes) {  // unknown_data_assoc.cpp:309-320
+        scan_measures.clear();
+        for (const Marker& m : tubes) scan_measures.push_back(Vector2D{m.x, m.y});
+        sensor_update_flag = true;
+    }
+    void main_loop() {  // slam.cpp:419-448 / unknown_data_assoc.cpp:402-429
+        switch (state_machine) {
+            case SLAMState::INIT:
+                slam_agent = EKF_SLAM(max_n_tubes);  // copy/move-assignment of a temporary, slam.cpp:428
+                state_machine = SLAMState::UPDATE;
+                break;
+            case SLAMState::UPDATE:
+                if (sensor_update_flag) {
+                    slam_agent.prediction(odometer.getCurrentTwist());
+                    if (unknown_assoc) slam_agent.data_association(scan_measures, known_list);
+                    else slam_agent.measurement(sensor_reading, visible_list, known_list);
+                    sensor_update_flag = false;
+                    state_update_flag = true;
+                }
+                break;
+            default:
+                throw std::logic_error("Invalid State");
+        }
+    }
+};
+
+int main(int argc, char** argv) {
+    if (argc != 3) { std::fprintf(stderr, "usage: slam_replay <log.txt> <out.txt>\n"); return 2; }
+    FILE* f = std::fopen(argv[1], "r");
+    if (!f) { std::perror("log"); return 2; }
+    int unknown = 0, n = 0, T = 0;
+    double wb = 0, wr = 0;
+    if (std::fscanf(f, "%d %d %d %lf %lf", &unknown, &n, &T, &wb, &wr) != 5) return 2;
+    try {
+        Odometer odo{wb, wr};
+        SLAM node(n, unknown != 0, odo);
+        node.main_loop();  // INIT tick
+        for (int t = 0; t < T; t++) {
+            int count = 0;
+            if (std::fscanf(f, "%la %la %d", &odo.delta_left, &odo.delta_right, &count) != 3) return 2;
+            std::vector<Marker> ms(count);
+            for (Marker& m : ms)
+                if (std::fscanf(f, "%d %la %la %d", &m.id, &m.x, &m.y, &m.add) != 4) return 2;
+            if (unknown) node.callback_scan_sensor(ms);
+            else node.callback_fake_sensor(ms);
+            node.main_loop();
+            node.main_loop();  // a timer tick without new sensor data must be a no-op on the filter
+        }
+        std::fclose(f);
+        // rule of five: a copy must carry the device state, the original must survive the copy's death
+        EKF_SLAM copy = node.slam_agent;
+        { EKF_SLAM moved = std::move(copy); copy = moved; }
+        const std::vector<double> s = copy.state(), c = node.slam_agent.covariance();
+        FILE* o = std::fopen(argv[2], "w");
+        if (!o) { std::perror("out"); return 2; }
+        std::fprintf(o, "%d\n", (int)s.size());
+        for (double v : s) std::fprintf(o, "%a\n", v);
+        for (double v : c) std::fprintf(o, "%a\n", v);
+        for (int i = 0; i < n; i++) std::fprintf(o, "%d\n", node.known_list[i] ? 1 : 0);
+        std::fprintf(o, "%a %a %a\n", node.slam_agent.getStateTheta(), node.slam_agent.getStateX(), node.slam_agent.getStateY());
+        const std::vector<double> lm = node.slam_agent.getStateLandmark();
+        std::fprintf(o, "%a\n", lm.empty() ? 0.0 : lm.back());
+        std::fclose(o);
+        // an empty object must refuse work loudly
+        EKF_SLAM empty;
+        bool threw = false;
+        try { empty.getStateX(); } catch (const std::logic_error&) { threw = true; }
+        if (!threw) { std::fprintf(stderr, "empty EKF_SLAM did not throw\n"); return 3; }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "slam_replay: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
