@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libekfslam_hip.so")
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 _bp = C.POINTER(C.c_uint8)
+_fp = C.POINTER(C.c_float)
 
 STATUS = {0: "EKF_OK", 1: "EKF_ERR_INVALID", 2: "EKF_ERR_NO_DEVICE", 3: "EKF_ERR_HIP", 4: "EKF_ERR_NOMEM",
           5: "EKF_ERR_STATE"}
@@ -33,6 +34,7 @@ SYMBOLS = [
     "ekf_batch_create", "ekf_batch_destroy", "ekf_batch_reset", "ekf_batch_device_bytes",
     "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_get_state", "ekf_batch_get_cov",
     "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
+    "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
 ]
 
 
@@ -110,6 +112,11 @@ def load():
         "ekf_batch_get_poses": [h, _dp],
         "ekf_batch_checksum": [h, _dp],
         "ekf_batch_set_tuning": [h, C.c_int, C.c_int, C.c_int],
+        "ekf_dense_create": [C.c_int, C.c_int, C.POINTER(h)],
+        "ekf_dense_destroy": [h],
+        "ekf_dense_set": [h, _fp, _fp, _fp],
+        "ekf_dense_propagate": [h, C.c_int, _dp],
+        "ekf_dense_get_sigma": [h, _fp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -325,3 +332,45 @@ class BatchEKF:
 
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_batch_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
+
+
+class DensePropagator:
+    """Sigma <- F Sigma F^T + Q for an arbitrary dense F, fp32 on the matrix cores (configs[3]):
+    the reference's `sigma = At*sigma*At.t() + Q` (ekf_slam.cpp:101-102) as two dense products."""
+
+    def __init__(self, N, device=-1):
+        self._lib = load()
+        self.N = int(N)
+        h = C.c_void_p()
+        _check(self._lib.ekf_dense_create(self.N, device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ekf_dense_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _f(self, a):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.shape != (self.N, self.N):
+            raise ValueError("matrices must be N x N")
+        return a, a.ctypes.data_as(_fp)
+
+    def set(self, F=None, Sigma=None, Q=None):
+        keep = [self._f(x) for x in (F, Sigma, Q)]
+        _check(self._lib.ekf_dense_set(self._h, keep[0][1], keep[1][1], keep[2][1]))
+
+    def propagate(self, iterations=1):
+        ms = C.c_double()
+        _check(self._lib.ekf_dense_propagate(self._h, int(iterations), C.byref(ms)))
+        return ms.value
+
+    @property
+    def sigma(self):
+        out = np.empty((self.N, self.N), dtype=np.float32)
+        _check(self._lib.ekf_dense_get_sigma(self._h, out.ctypes.data_as(_fp)))
+        return out

@@ -1,0 +1,14 @@
+// ekf_dense.hpp -- launcher of the fp32 MFMA GEMM used by the dense covariance propagation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace ekf {
+constexpr int kDenseTile = 128;  // ld must be a multiple of this
+// C[ld x ld] = A * B (+ Qadd), all row-major fp32 with zero padding up to ld.
+// b_transposed: B is supplied as Bt[j][k] (i.e. C = A * Bt^T).
+void launch_dense_gemm(const float* A, const float* B, float* C, const float* Qadd, int ld, bool b_transposed,
+                       hipStream_t s);
+size_t dense_gemm_lds_bytes(bool b_transposed);
+hipError_t dense_gemm_prepare();  // raises the dynamic-LDS limit of both instantiations (66 KB > 64 KB default)
+}  // namespace ekf

@@ -151,6 +151,21 @@ ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]);
 ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal, int group_rows);
 ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal, int group_rows);
 
+/* ---- dense general-F covariance propagation, fp32 on the matrix cores (BASELINE.json configs[3]) ----
+ * Sigma <- F * Sigma * F^T + Q for an ARBITRARY dense F: the reference's expression
+ * `sigma = At*sigma*At.t() + Q` (ekf_slam.cpp:101-102) as Armadillo executes it (two dense N^3
+ * products).  The filter's own At = I + A never needs this (ekf_predict is O(N)); the entry point
+ * serves motion models with a dense Jacobian and is checked against fp64 (tolerance 1e-4 per block).
+ * All matrices are row-major N x N fp32 host buffers. */
+typedef struct ekf_dense_s* ekf_dense_handle;
+ekf_status ekf_dense_create(int N, int device, ekf_dense_handle* out);
+ekf_status ekf_dense_destroy(ekf_dense_handle h);
+/* Any of F, Sigma, Q may be NULL to keep the current device contents (initially all zero). */
+ekf_status ekf_dense_set(ekf_dense_handle h, const float* F, const float* Sigma, const float* Q);
+/* Applies the propagation `iterations` times; elapsed_ms (nullable) = HIP-event time of the launches. */
+ekf_status ekf_dense_propagate(ekf_dense_handle h, int iterations, double* elapsed_ms);
+ekf_status ekf_dense_get_sigma(ekf_dense_handle h, float* out);
+
 #ifdef __cplusplus
 }
 #endif
