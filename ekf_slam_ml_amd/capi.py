@@ -34,6 +34,7 @@ SYMBOLS = [
     "ekf_batch_create", "ekf_batch_destroy", "ekf_batch_reset", "ekf_batch_device_bytes",
     "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_get_state", "ekf_batch_get_cov",
     "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
+    "ekf_set_update_mode", "ekf_batch_set_update_mode",
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
 ]
 
@@ -112,6 +113,8 @@ def load():
         "ekf_batch_get_poses": [h, _dp],
         "ekf_batch_checksum": [h, _dp],
         "ekf_batch_set_tuning": [h, C.c_int, C.c_int, C.c_int],
+        "ekf_set_update_mode": [h, C.c_int],
+        "ekf_batch_set_update_mode": [h, C.c_int],
         "ekf_dense_create": [C.c_int, C.c_int, C.POINTER(h)],
         "ekf_dense_destroy": [h],
         "ekf_dense_set": [h, _fp, _fp, _fp],
@@ -263,6 +266,10 @@ class EKF_SLAM:
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
 
+    def set_update_mode(self, max_pending_corrections=0):
+        """0 = eager covariance stream per correction; k > 0 = delayed rank-2k update (flush every k)."""
+        _check(self._lib.ekf_set_update_mode(self._h, int(max_pending_corrections)))
+
 
 class BatchEKF:
     """B independent filters on one GPU, replaying a device-resident known-association log."""
@@ -332,6 +339,10 @@ class BatchEKF:
 
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_batch_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
+
+    def set_update_mode(self, max_pending_corrections=0):
+        """0 = eager covariance stream per correction; k > 0 = delayed rank-2k update (flush every k)."""
+        _check(self._lib.ekf_batch_set_update_mode(self._h, int(max_pending_corrections)))
 
 
 class DensePropagator:

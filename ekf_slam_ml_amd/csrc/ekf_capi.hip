@@ -99,6 +99,58 @@ struct Pool {
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 
+    // delayed rank-2k update (0 = eager): pending factor store + ping-pong state buffer
+    double* Uf = nullptr;
+    double* Vf = nullptr;
+    double* state_alt = nullptr;
+    int pend_cap = 0, pend_count = 0;
+
+    ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count}; }
+
+    ekf_status set_update_mode(int max_pending_corrections) {
+        EKFC(use());
+        EKFC(flush());
+        HIPC(hipStreamSynchronize(stream));
+        for (double** p : {&Uf, &Vf, &state_alt})
+            if (*p) { HIPC(hipFree(*p)); *p = nullptr; }
+        pend_cap = 0;
+        if (max_pending_corrections <= 0) return EKF_OK;
+        int cap = 2 * max_pending_corrections;
+        if (cap > ekf::max_pending()) cap = ekf::max_pending();
+        const size_t cnt = (size_t)pv.B * cap * pv.ld;
+        HIPC(hipMalloc((void**)&Uf, cnt * sizeof(double)));
+        HIPC(hipMalloc((void**)&Vf, cnt * sizeof(double)));
+        HIPC(hipMalloc((void**)&state_alt, (size_t)pv.B * pv.ld * sizeof(double)));
+        HIPC(hipMemsetAsync(state_alt, 0, (size_t)pv.B * pv.ld * sizeof(double), stream));
+        pend_cap = cap;
+        return EKF_OK;
+    }
+
+    // fold every pending correction into Sigma_base (no-op in eager mode)
+    ekf_status flush() {
+        if (pend_count > 0) {
+            ekf::launch_flush(pv, pending(), tuning, stream);
+            HIPC(hipGetLastError());
+            pend_count = 0;
+        }
+        return EKF_OK;
+    }
+
+    // one landmark correction, eager (gain + covariance stream) or delayed (gain only, factors appended)
+    ekf_status correct(const ekf::CmdSrc& src) {
+        if (pend_cap > 0 && src.mode != ekf::SRC_ASSOC) {
+            if (pend_count + 2 > pend_cap) EKFC(flush());
+            ekf::launch_gain_delayed(pv, src, pending(), state_alt, stream);
+            std::swap(pv.state, state_alt);
+            pend_count += 2;
+        } else {
+            EKFC(flush());
+            ekf::launch_gain(pv, src, stream);
+            ekf::launch_rank2(pv, tuning, stream);
+        }
+        return EKF_OK;
+    }
+
     ekf_status use() {
         HIPC(hipSetDevice(device));
         return EKF_OK;
@@ -151,6 +203,7 @@ struct Pool {
 
     ekf_status reset() {
         EKFC(use());
+        pend_count = 0;  // pending factors of the old run are dropped with it
         ekf::launch_init(pv, stream);
         HIPC(hipGetLastError());
         init_flag = 0;
@@ -161,7 +214,8 @@ struct Pool {
         if (device >= 0) (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
         void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, scores, meas_dev,
-                        assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init};
+                        assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
+                        Uf, Vf, state_alt};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();
@@ -214,6 +268,7 @@ struct Pool {
     ekf_status get_cov(int b, double* out) {
         if (!out || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "get_cov: bad argument");
         EKFC(use());
+        EKFC(flush());
         const size_t w = sizeof(double) * pv.N;
         EKFC(stage_out.reserve(w * pv.N));
         HIPC(hipMemcpy2DAsync(stage_out.host, w, pv.sigma + (size_t)b * pv.sigma_stride, sizeof(double) * pv.ld, w,
@@ -226,6 +281,7 @@ struct Pool {
     ekf_status set_cov(int b, const double* in) {
         if (!in || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "set_cov: bad argument");
         EKFC(use());
+        EKFC(flush());
         const size_t w = sizeof(double) * pv.N;
         EKFC(stage_in.reserve(w * pv.N));
         EKFC(stage_in.wait());
@@ -327,7 +383,9 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
                  a.pv.p.straight_eps};
     EKFC(ekf_create(a.pv.n, &p, a.device, out));
     Pool& c = (*out)->pool;
+    EKFC(a.flush());
     EKFC(a.sync());
+    if (a.pend_cap > 0) EKFC(c.set_update_mode(a.pend_cap / 2));
     HIPC(hipMemcpyAsync(c.pv.sigma, a.pv.sigma, sizeof(double) * a.pv.sigma_stride, hipMemcpyDeviceToDevice, c.stream));
     HIPC(hipMemcpyAsync(c.pv.state, a.pv.state, sizeof(double) * a.pv.ld, hipMemcpyDeviceToDevice, c.stream));
     c.init_flag = a.init_flag;
@@ -339,7 +397,7 @@ ekf_status ekf_predict(ekf_handle h, double dtheta, double dx) {
     if (!h) return fail(EKF_ERR_INVALID, "ekf_predict: null handle");
     Pool& P = h->pool;
     EKFC(P.use());
-    ekf::launch_predict(P.pv, nullptr, dtheta, dx, P.stream);
+    ekf::launch_predict(P.pv, nullptr, dtheta, dx, P.pending(), P.stream);
     return checked_launch();
 }
 
@@ -358,8 +416,7 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     for (int i = 0; i < n; i++) {  // ekf_slam.cpp:132-194, ascending landmark order
         if (!visible[i]) continue;
         src.lm_imm = i;
-        ekf::launch_gain(P.pv, src, P.stream);
-        ekf::launch_rank2(P.pv, P.tuning, P.stream);
+        EKFC(P.correct(src));
     }
     return checked_launch();
 }
@@ -374,6 +431,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         if (known[i]) known_count++; else break;
     }
     if (J == 0) return EKF_OK;
+    EKFC(P.flush());  // the scoring kernel reads Sigma directly
     EKFC(P.ensure_meas_capacity(J));
     EKFC(P.upload(P.meas_dev, meas_xy, sizeof(double) * 2 * J));
     ekf::launch_assoc_begin(P.pv, nullptr, known_count, P.stream);
@@ -403,6 +461,7 @@ ekf_status ekf_maha_scores(ekf_handle h, double meas_x, double meas_y, int M, do
     if (M > P.pv.n) return fail(EKF_ERR_INVALID, "ekf_maha_scores: M exceeds the number of landmarks");
     if (M == 0) return EKF_OK;
     EKFC(P.use());
+    EKFC(P.flush());
     EKFC(P.ensure_meas_capacity(1));
     const double m[2] = {meas_x, meas_y};
     EKFC(P.upload(P.meas_dev, m, sizeof(m)));
@@ -508,6 +567,16 @@ ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int non
     return EKF_OK;
 }
 
+ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    return hb->pool.set_update_mode(max_pending_corrections);
+}
+
+ekf_status ekf_set_update_mode(ekf_handle h, int max_pending_corrections) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    return h->pool.set_update_mode(max_pending_corrections);
+}
+
 ekf_status ekf_batch_upload_known_log(ekf_batch_handle hb, const ekf_known_log* log) {
     if (!hb || !log || !log->twist || !log->lm_idx || !log->z_xy || !log->init_xy || log->T <= 0 || log->vmax < 0)
         return fail(EKF_ERR_INVALID, "ekf_batch_upload_known_log: bad argument");
@@ -564,19 +633,30 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
                 launches++;
                 corrections += P.slot_active[(size_t)t * vmax + v];
             }
+    const bool delayed = P.pend_cap > 0;
+    // worst-case number of covariance passes (rank-2 launches, or flushes in delayed mode) for the events
+    const size_t max_passes = delayed ? launches / (size_t)(P.pend_cap / 2) + 2 : launches;
     hipEvent_t* ev = nullptr;
     if (time_kernels && launches) {
-        ev = P.events(2 * launches);
+        ev = P.events(2 * max_passes);
         if (!ev) return fail(EKF_ERR_HIP, "hipEventCreate failed");
     }
     HIPC(hipEventRecord(P.ev_begin, P.stream));
     size_t k = 0;
+    auto timed_flush = [&]() -> ekf_status {
+        if (P.pend_count == 0) return EKF_OK;
+        if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
+        EKFC(P.flush());
+        if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
+        k++;
+        return EKF_OK;
+    };
     ekf::CmdSrc src{};
     src.mode = ekf::SRC_COMPACT_LOG;
     src.vmax = vmax;
     src.fresh_pose = 0;
     for (int t = t_begin; t < t_end; t++) {
-        ekf::launch_predict(P.pv, P.log_twist + (size_t)t * B * 2, 0.0, 0.0, P.stream);  // prediction()
+        ekf::launch_predict(P.pv, P.log_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream);  // prediction()
         ekf::launch_measure_begin(P.pv, P.log_init, !P.init_flag, P.stream);               // measurement() top
         P.init_flag = 1;
         src.lm_idx = P.log_lm + (size_t)t * B * vmax;
@@ -584,13 +664,20 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
         for (int v = 0; v < vmax; v++) {
             if (P.slot_active[(size_t)t * vmax + v] == 0) continue;
             src.v = v;
-            ekf::launch_gain(P.pv, src, P.stream);
-            if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
-            ekf::launch_rank2(P.pv, P.tuning, P.stream);
-            if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
-            k++;
+            if (delayed) {
+                if (P.pend_count + 2 > P.pend_cap) EKFC(timed_flush());
+                EKFC(P.correct(src));
+            } else {
+                ekf::launch_gain(P.pv, src, P.stream);
+                if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
+                ekf::launch_rank2(P.pv, P.tuning, P.stream);
+                if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
+                k++;
+            }
         }
     }
+    if (delayed) EKFC(timed_flush());  // every run leaves Sigma materialised
+    const size_t passes = k;
     HIPC(hipEventRecord(P.ev_end, P.stream));
     EKFC(checked_launch());
     HIPC(hipStreamSynchronize(P.stream));
@@ -599,17 +686,19 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
         HIPC(hipEventElapsedTime(&ms, P.ev_begin, P.ev_end));
         stats->elapsed_ms = ms;
         stats->rank2_ms = 0.0;
-        stats->rank2_launches = (long long)launches;
+        stats->rank2_launches = (long long)passes;
         if (ev)
-            for (size_t i = 0; i < launches; i++) {
+            for (size_t i = 0; i < passes; i++) {
                 float m = 0.f;
                 HIPC(hipEventElapsedTime(&m, ev[2 * i], ev[2 * i + 1]));
                 stats->rank2_ms += m;
             }
         stats->corrections = corrections;
         stats->filter_steps = (long long)B * (t_end - t_begin);
-        const double per_corr = 2.0 * sizeof(double) * (double)P.pv.N * (double)P.pv.N;
-        stats->rank2_bytes_per_launch = launches ? per_corr * (double)corrections / (double)launches : 0.0;
+        // algorithmic bytes of one covariance pass: every filter's Sigma read + written once
+        const double per_pass = 2.0 * sizeof(double) * (double)P.pv.N * (double)P.pv.N;
+        stats->rank2_bytes_per_launch =
+            delayed ? per_pass * (double)B : (launches ? per_pass * (double)corrections / (double)launches : 0.0);
     }
     return EKF_OK;
 }
@@ -637,6 +726,7 @@ ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]) {
     if (!hb || !out) return fail(EKF_ERR_INVALID, "null argument");
     Pool& P = hb->pool;
     EKFC(P.use());
+    EKFC(P.flush());
     HIPC(hipMemsetAsync(P.digest_dev, 0, sizeof(double) * 4 * P.pv.B, P.stream));
     ekf::launch_checksum(P.pv, P.digest_dev, P.stream);
     EKFC(checked_launch());

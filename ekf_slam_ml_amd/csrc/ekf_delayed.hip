@@ -1,0 +1,256 @@
+// ekf_delayed.hip -- delayed rank-2k covariance update.
+//
+// The eager correction streams Sigma once per landmark (16 N^2 bytes, ekf_slam.cpp:191-192).  Here the
+// rank-2 terms are kept as factors, Sigma = Sigma_base - sum_j U[j] V[j]^T, every quantity a correction
+// needs from Sigma (5 rows, 5 columns, the 5x5 block) is reconstructed on the fly in O(k N), and
+// Sigma_base is rewritten once per FLUSH.  Declared algorithmic bytes:
+//   per correction   2*8*N*(k_pending) (read U, V)  + 10*8*N (base gathers) + 4*8*N (append)
+//   per flush        2*8*N^2 + 2*8*N*k
+// The terms are subtracted pair by pair in correction order.  The inner loops use fused multiply-adds
+// (the flush is compute-bound in fp64 beyond ~16 pending corrections; the rest of the library is built
+// -ffp-contract=off), so the delayed path matches the eager path to rounding, not bit for bit.
+#include "ekf_kernels.hpp"
+
+namespace ekf {
+
+constexpr int kMaxPending = 128;
+
+// ---------------------------------------------------------------------------------------------
+// One landmark correction in delayed mode: ekf_slam.cpp:137-187 without the covariance stream.
+// grid (ceil(ld/512), B).  Reads: state (in), Sigma_base, U/V rows [0, count); writes: U/V rows
+// count, count+1, state_out, rec.  No buffer is both read and written -> race-free across workgroups.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, Pending pend,
+                                                      double* __restrict__ state_out) {
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int N = pv.N, ld = pv.ld;
+    const int rc = pend.count;
+    __shared__ double sh_U5[5 * kMaxPending];
+    __shared__ double sh_V5[5 * kMaxPending];
+    __shared__ double sh_S55[25];
+    __shared__ double sh_H[10];
+    __shared__ double sh_Si[4];
+    __shared__ double sh_nu[2];
+
+    // a lane owns the two consecutive indices r, r+1 (16-B accesses); a workgroup covers 512 indices
+    const int r = 2 * (blockIdx.x * 256 + tid);
+    const double* st = pv.state + (size_t)b * ld;
+    double* so = state_out + (size_t)b * ld;
+    double* Ub = pend.U + (size_t)b * pend.cap * ld;
+    double* Vb = pend.V + (size_t)b * pend.cap * ld;
+    const double2_t zero2 = {0.0, 0.0};
+
+    int lm = -1;
+    double sx = 0.0, sy = 0.0;
+    if (src.mode == SRC_SENSOR_VECTOR) {
+        lm = src.lm_imm;
+        sx = src.sensor[(size_t)b * 2 * pv.n + 2 * lm];
+        sy = src.sensor[(size_t)b * 2 * pv.n + 2 * lm + 1];
+    } else if (src.mode == SRC_COMPACT_LOG) {
+        const size_t slot = (size_t)b * src.vmax + src.v;
+        lm = src.lm_idx[slot];
+        if (lm >= 0) {
+            sx = src.z_xy[slot * 2];
+            sy = src.z_xy[slot * 2 + 1];
+        }
+    }
+    if (lm < 0 || lm >= pv.n) {  // nothing to correct: carry the state over, append a zero pair
+        if (r < ld) {
+            *reinterpret_cast<double2_t*>(so + r) = *reinterpret_cast<const double2_t*>(st + r);
+            *reinterpret_cast<double2_t*>(Ub + (size_t)rc * ld + r) = zero2;
+            *reinterpret_cast<double2_t*>(Ub + (size_t)(rc + 1) * ld + r) = zero2;
+            *reinterpret_cast<double2_t*>(Vb + (size_t)rc * ld + r) = zero2;
+            *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + 1) * ld + r) = zero2;
+        }
+        if (blockIdx.x == 0 && tid == 0) pv.rec[b].active = 0;
+        return;
+    }
+
+    const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    for (int idx = tid; idx < 5 * rc; idx += 256) {
+        const int k = idx / rc, j = idx - k * rc;
+        const int c = idx5(k, lm);
+        sh_U5[k * kMaxPending + j] = Ub[(size_t)j * ld + c];
+        sh_V5[k * kMaxPending + j] = Vb[(size_t)j * ld + c];
+    }
+    __syncthreads();
+    if (tid < 25) {
+        const int k = tid / 5, l = tid % 5;
+        double v = Sg[(size_t)idx5(k, lm) * ld + idx5(l, lm)];
+        for (int j = 0; j < rc; j += 2)
+            v = __builtin_fma(-sh_U5[k * kMaxPending + j + 1], sh_V5[l * kMaxPending + j + 1],
+                              __builtin_fma(-sh_U5[k * kMaxPending + j], sh_V5[l * kMaxPending + j], v));
+        sh_S55[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double theta, x, y;
+        if (src.fresh_pose) {
+            theta = st[0]; x = st[1]; y = st[2];
+        } else {
+            const double* sn = pv.snap + (size_t)b * 4;
+            theta = sn[0]; x = sn[1]; y = sn[2];
+        }
+        MeasTerms m;
+        measurement_terms(st[2 * lm + 3], st[2 * lm + 4], sx, sy, theta, x, y, m);
+        double S55[5][5], S[2][2], Si[2][2];
+        for (int k = 0; k < 5; k++)
+            for (int l = 0; l < 5; l++) S55[k][l] = sh_S55[k * 5 + l];
+        innovation_cov(S55, m.H, pv.p.r_meas, S);
+        inv2(S, Si);
+        for (int a = 0; a < 2; a++)
+            for (int k = 0; k < 5; k++) sh_H[a * 5 + k] = m.H[a][k];
+        sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
+        sh_nu[0] = m.z0 - m.zh0;                   // :182
+        sh_nu[1] = normalize_angle(m.z1 - m.zh1);  // :183
+        if (blockIdx.x == 0) {
+            CorrRec rcd;
+            rcd.nu0 = sh_nu[0]; rcd.nu1 = sh_nu[1]; rcd.active = 1; rcd.lm = lm;
+            pv.rec[b] = rcd;
+        }
+    }
+    __syncthreads();
+    if (r >= ld) return;
+
+    double2_t kv0 = zero2, kv1 = zero2, gv0 = zero2, gv1 = zero2, snew = zero2;
+    if (r < N) {
+        // current Sigma(r, c5[k]) and Sigma(c5[k], r) for r and r+1: base entries minus the pending pairs
+        const bool two = r + 1 < N;  // N is odd: the last lane owns one real index and one pad index
+        double2_t p[5], g[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int c = idx5(k, lm);
+            p[k].x = Sg[(size_t)r * ld + c];
+            p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
+            g[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)c * ld + r);
+        }
+        for (int j = 0; j < rc; j += 2) {
+            const double2_t ua = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
+            const double2_t ub = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
+            const double2_t va = *reinterpret_cast<const double2_t*>(Vb + (size_t)j * ld + r);
+            const double2_t vb = *reinterpret_cast<const double2_t*>(Vb + (size_t)(j + 1) * ld + r);
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const double v5a = sh_V5[k * kMaxPending + j], v5b = sh_V5[k * kMaxPending + j + 1];
+                const double u5a = sh_U5[k * kMaxPending + j], u5b = sh_U5[k * kMaxPending + j + 1];
+                p[k].x = __builtin_fma(-ub.x, v5b, __builtin_fma(-ua.x, v5a, p[k].x));
+                p[k].y = __builtin_fma(-ub.y, v5b, __builtin_fma(-ua.y, v5a, p[k].y));
+                g[k].x = __builtin_fma(-u5b, vb.x, __builtin_fma(-u5a, va.x, g[k].x));
+                g[k].y = __builtin_fma(-u5b, vb.y, __builtin_fma(-u5a, va.y, g[k].y));
+            }
+        }
+        double2_t sht0 = zero2, sht1 = zero2;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            sht0.x += p[k].x * sh_H[k];     sht0.y += p[k].y * sh_H[k];
+            sht1.x += p[k].x * sh_H[5 + k]; sht1.y += p[k].y * sh_H[5 + k];
+            gv0.x += sh_H[k] * g[k].x;      gv0.y += sh_H[k] * g[k].y;
+            gv1.x += sh_H[5 + k] * g[k].x;  gv1.y += sh_H[5 + k] * g[k].y;
+        }
+        kv0.x = sht0.x * sh_Si[0] + sht1.x * sh_Si[2];  // K = (Sigma H^T) S^-1   :178
+        kv1.x = sht0.x * sh_Si[1] + sht1.x * sh_Si[3];
+        kv0.y = sht0.y * sh_Si[0] + sht1.y * sh_Si[2];
+        kv1.y = sht0.y * sh_Si[1] + sht1.y * sh_Si[3];
+        const double2_t sv = *reinterpret_cast<const double2_t*>(st + r);
+        snew.x = sv.x + (kv0.x * sh_nu[0] + kv1.x * sh_nu[1]);  // :186
+        snew.y = sv.y + (kv0.y * sh_nu[0] + kv1.y * sh_nu[1]);
+        if (r == 0) snew.x = normalize_angle(snew.x);           // :187
+        if (!two) { kv0.y = 0.0; kv1.y = 0.0; gv0.y = 0.0; gv1.y = 0.0; snew.y = 0.0; }  // pad stays 0
+    }
+    *reinterpret_cast<double2_t*>(Ub + (size_t)rc * ld + r) = kv0;
+    *reinterpret_cast<double2_t*>(Ub + (size_t)(rc + 1) * ld + r) = kv1;
+    *reinterpret_cast<double2_t*>(Vb + (size_t)rc * ld + r) = gv0;
+    *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + 1) * ld + r) = gv1;
+    *reinterpret_cast<double2_t*>(so + r) = snew;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flush: Sigma_base(r, c) -= sum over pending pairs (U[j](r) V[j](c) + U[j+1](r) V[j+1](c)).
+// Same streaming structure as k_rank2 (strip of 256 double2 columns, 16-row register groups, loads
+// before stores, non-temporal), with a loop over the pairs: U values are wave-uniform (scalar loads),
+// V values are per lane and come from L2 (count x 16 KB per filter).  2*8*N^2 bytes, 2*count*N^2 flop.
+// ---------------------------------------------------------------------------------------------
+template <int U_ROWS, bool NT>
+__global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const double* __restrict__ Uall,
+                                               const double* __restrict__ Vall, int N, int ld, size_t sigma_stride,
+                                               int cap, int count, int rows_per_block) {
+    const int b = blockIdx.z;
+    const int ld2n = ld >> 1;
+    const int c2 = blockIdx.x * 256 + threadIdx.x;
+    const int row_begin = blockIdx.y * rows_per_block;
+    const int row_end = min(N, row_begin + rows_per_block);
+    if (c2 >= ld2n) return;
+    const double* __restrict__ Ub = Uall + (size_t)b * cap * ld;
+    const double2_t* __restrict__ Vb = reinterpret_cast<const double2_t*>(Vall + (size_t)b * cap * ld) + c2;
+    double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + c2;
+
+    int r = row_begin;
+    for (; r + U_ROWS <= row_end; r += U_ROWS) {
+        double2_t a[U_ROWS];
+#pragma unroll
+        for (int u = 0; u < U_ROWS; u++) {
+            if constexpr (NT) a[u] = __builtin_nontemporal_load(col + (size_t)(r + u) * ld2n);
+            else a[u] = col[(size_t)(r + u) * ld2n];
+        }
+        double2_t v0 = Vb[0], v1 = Vb[ld2n];
+        for (int j = 0; j < count; j += 2) {
+            // V of the NEXT pair is requested before this pair's FMAs (the last trip re-reads pair 0)
+            const int jn = j + 2 < count ? j + 2 : 0;
+            const double2_t v0n = Vb[(size_t)jn * ld2n], v1n = Vb[(size_t)(jn + 1) * ld2n];
+            const double* __restrict__ u0 = Ub + (size_t)j * ld + r;  // wave-uniform -> scalar loads
+            const double* __restrict__ u1 = u0 + ld;
+#pragma unroll
+            for (int u = 0; u < U_ROWS; u++) {
+                const double k0 = -u0[u], k1 = -u1[u];
+                a[u].x = __builtin_fma(k1, v1.x, __builtin_fma(k0, v0.x, a[u].x));
+                a[u].y = __builtin_fma(k1, v1.y, __builtin_fma(k0, v0.y, a[u].y));
+            }
+            v0 = v0n;
+            v1 = v1n;
+        }
+#pragma unroll
+        for (int u = 0; u < U_ROWS; u++) {
+            if constexpr (NT) __builtin_nontemporal_store(a[u], col + (size_t)(r + u) * ld2n);
+            else col[(size_t)(r + u) * ld2n] = a[u];
+        }
+    }
+    for (; r < row_end; r++) {
+        double2_t a = col[(size_t)r * ld2n];
+        for (int j = 0; j < count; j += 2) {
+            const double2_t v0 = Vb[(size_t)j * ld2n], v1 = Vb[(size_t)(j + 1) * ld2n];
+            const double k0 = Ub[(size_t)j * ld + r], k1 = Ub[(size_t)(j + 1) * ld + r];
+            a.x = a.x - (k0 * v0.x + k1 * v1.x);
+            a.y = a.y - (k0 * v0.y + k1 * v1.y);
+        }
+        col[(size_t)r * ld2n] = a;
+    }
+}
+
+void launch_gain_delayed(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(k_gain_delayed, dim3((pv.ld / 2 + 255) / 256, pv.B), dim3(256), 0, s, pv, src, pend, state_out);
+}
+
+void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s) {
+    if (pend.count <= 0) return;
+    const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
+    const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
+    int rows = t.rows_per_block > 0 ? t.rows_per_block : 32;
+    const long long strips = (long long)pv.B * ((pv.ld / 2 + 255) / 256);
+    if (t.rows_per_block <= 0 && strips * pv.N < 256LL * 8 * 32) rows = 8;
+    dim3 grid((pv.ld / 2 + 255) / 256, (pv.N + rows - 1) / rows, pv.B);
+#define EKF_FL_ARGS pv.sigma, pend.U, pend.V, pv.N, pv.ld, pv.sigma_stride, pend.cap, pend.count, rows
+    if (rows >= 16) {
+        if (nt) hipLaunchKernelGGL((k_flush<16, true>), grid, dim3(256), 0, s, EKF_FL_ARGS);
+        else hipLaunchKernelGGL((k_flush<16, false>), grid, dim3(256), 0, s, EKF_FL_ARGS);
+    } else {
+        if (nt) hipLaunchKernelGGL((k_flush<8, true>), grid, dim3(256), 0, s, EKF_FL_ARGS);
+        else hipLaunchKernelGGL((k_flush<8, false>), grid, dim3(256), 0, s, EKF_FL_ARGS);
+    }
+#undef EKF_FL_ARGS
+}
+
+int max_pending() { return kMaxPending; }
+
+}  // namespace ekf

@@ -6,9 +6,6 @@
 
 namespace ekf {
 
-typedef double double2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ int idx5(int k, int lm) { return k < 3 ? k : 3 + 2 * lm + (k - 3); }
 
 // ---------------------------------------------------------------------------------------------
 // Constructor state, ekf_slam.cpp:27-53: Sigma0 = blockdiag(0_3x3, sigma0 * I_2n), state = 0.
@@ -59,7 +56,7 @@ __global__ __launch_bounds__(256) void k_init(PoolView pv) {
 constexpr int kPredictThreads = 1024;
 
 __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const double* twist_dev, double dth_imm,
-                                                            double dx_imm) {
+                                                            double dx_imm, Pending pend) {
     const int b = blockIdx.x;
     const int N = pv.N, ld = pv.ld;
     double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
@@ -93,6 +90,17 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
         Sg[(size_t)2 * ld + k] = a20 * s0 + s2;
         rowk[1] = r0 * a10 + r1;
         rowk[2] = r0 * a20 + r2;
+    }
+    // Delayed-update mode: Sigma = Sigma_base - sum_j u_j v_j^T with pending factors; At (.) At^T maps the
+    // base (above) and every factor: u <- At u, v <- At v (only entries 1 and 2 change).
+    for (int j = threadIdx.x; j < pend.count; j += kPredictThreads) {
+        double* u = pend.U + ((size_t)b * pend.cap + j) * ld;
+        double* v = pend.V + ((size_t)b * pend.cap + j) * ld;
+        const double u0_ = u[0], v0_ = v[0];
+        u[1] = a10 * u0_ + u[1];
+        u[2] = a20 * u0_ + u[2];
+        v[1] = a10 * v0_ + v[1];
+        v[2] = a20 * v0_ + v[2];
     }
     if (threadIdx.x == 0) {
         st[0] = theta + u0;  // :99 -- theta is NOT wrapped after the prediction
@@ -522,8 +530,9 @@ void launch_init(const PoolView& pv, hipStream_t s) {
     hipLaunchKernelGGL(k_init, grid, dim3(256), 0, s, pv);
 }
 
-void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, double dx, hipStream_t s) {
-    hipLaunchKernelGGL(k_predict, dim3(pv.B), dim3(kPredictThreads), 0, s, pv, twist_dev, dtheta, dx);
+void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, double dx, const Pending& pend,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_predict, dim3(pv.B), dim3(kPredictThreads), 0, s, pv, twist_dev, dtheta, dx, pend);
 }
 
 void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init, hipStream_t s) {

@@ -22,6 +22,23 @@ namespace ekf {
 constexpr double kPI = 3.14159265358979323846;  // rigid2d/include/rigid2d/rigid2d.hpp:13
 constexpr int kWave = 64;
 
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// the five non-zero columns of Hj for landmark lm: {0, 1, 2, 3+2lm, 4+2lm} (ekf_slam.cpp:164-170)
+__host__ __device__ __forceinline__ int idx5(int k, int lm) { return k < 3 ? k : 3 + 2 * lm + (k - 3); }
+
+// Delayed ("rank-2k") covariance update: Sigma = Sigma_base - sum_{j < count} U[j] V[j]^T, where every
+// landmark correction appends the pair (K(:,0), (H Sigma)(0,:)), (K(:,1), (H Sigma)(1,:)) instead of
+// streaming Sigma; k_flush folds all pending pairs into Sigma_base in ONE pass (16 N^2 bytes per FLUSH
+// instead of per correction).  U and V are [B][cap][ld]; count is the same for every filter of a pool
+// (a filter with nothing to correct in a slot appends a zero pair).
+struct Pending {
+    double* U;
+    double* V;
+    int cap;
+    int count;
+};
+
 struct Params {
     double sigma0_landmark, q_pose, r_meas, gate_new, gate_update, straight_eps;
 };
@@ -139,7 +156,14 @@ struct Rank2Tuning {
 
 void launch_init(const PoolView& pv, hipStream_t s);
 // prediction(): twist = imm (dtheta, dx) when twist_dev == nullptr, else twist_dev[b*2 + {0,1}]
-void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, double dx, hipStream_t s);
+void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, double dx, const Pending& pend,
+                    hipStream_t s);
+// Delayed mode: one kernel per correction (no covariance stream); reads state from pv.state, writes the
+// corrected state to state_out (ping-pong) and appends the factor pair at rows pend.count, pend.count+1.
+void launch_gain_delayed(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
+                         hipStream_t s);
+// Sigma_base -= sum_j U[j] V[j]^T for j < pend.count (count even); the caller then resets count to 0.
+void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s);
 // top of measurement(): pose snapshot (+ first-call landmark initialisation from init_xy [B][2n])
 void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init, hipStream_t s);
 void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s);
@@ -153,6 +177,7 @@ void launch_assoc_decide(const PoolView& pv, const double* meas, const double* s
                          int out_stride, int j, hipStream_t s);
 // out[b][4] += {sum state, sum |state|, sum sigma, sum |sigma|}; caller zeroes out first
 void launch_checksum(const PoolView& pv, double* out, hipStream_t s);
+int max_pending();  // capacity limit of the delayed-update factor store (rows of U / V per filter)
 void launch_gather_poses(const PoolView& pv, double* out, hipStream_t s);
 
 }  // namespace ekf

@@ -151,6 +151,16 @@ ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]);
 ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal, int group_rows);
 ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal, int group_rows);
 
+/* Covariance update mode.  0 (default) = EAGER: every landmark correction streams Sigma once
+ * (16 N^2 bytes) -- the contract path the roofline is quoted on.  k > 0 = DELAYED rank-2k update
+ * (SURVEY.md section 8(f) f2): up to k corrections are kept as low-rank factors
+ * (Sigma = Sigma_base - sum K_j (H Sigma)_j), the rows/columns a correction needs are rebuilt on the
+ * fly, prediction() maps the factors, and Sigma is rewritten once per k corrections (and before any
+ * call that reads it: get_cov, checksum, clone, data_association, maha_scores).  Same results to
+ * rounding (tested at 1e-9); k is capped at 64. */
+ekf_status ekf_set_update_mode(ekf_handle h, int max_pending_corrections);
+ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections);
+
 /* ---- dense general-F covariance propagation, fp32 on the matrix cores (BASELINE.json configs[3]) ----
  * Sigma <- F * Sigma * F^T + Q for an ARBITRARY dense F: the reference's expression
  * `sigma = At*sigma*At.t() + Q` (ekf_slam.cpp:101-102) as Armadillo executes it (two dense N^3
