@@ -68,11 +68,19 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
+    # one process per GPU; EKF_DIST_BACKEND=gloo is a rehearsal mode that lets several ranks share one GPU
+    # (RCCL refuses two ranks on one device) -- the reduction then runs on CPU tensors
+    backend = os.environ.get("EKF_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from ekf_slam_ml_amd import capi, synth
 
     n = a.landmarks
@@ -112,7 +120,7 @@ def main():
     corr = float(st["corrections"])
     fsteps = float(st["filter_steps"])
     # the only collective of the job: RCCL all-reduce of three scalars (max wall, summed work)
-    wall, corr, fsteps = shard.reduce_throughput(wall, corr, fsteps, device="cuda")
+    wall, corr, fsteps = shard.reduce_throughput(wall, corr, fsteps, device=red_dev)
     eager_state = [bt.state(b) for b in range(min(B, 4))] if rank == 0 else None
 
     # Second, separately reported leg: the SAME K steps with the delayed
@@ -130,7 +138,7 @@ def main():
         t1 = time.perf_counter()
         fence()
         dwall, dcorr, _ = shard.reduce_throughput(t1 - t0, float(sd["corrections"]), float(sd["filter_steps"]),
-                                                  device="cuda")
+                                                  device=red_dev)
         if rank == 0:
             kk = float(a.delayed_k)
             Nf = float(N)

@@ -15,3 +15,8 @@ python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.txt
 cat $OUT/summary.txt
 # keep only the small files (the per-dispatch CSVs can be large)
 find $OUT -name '*.csv' -size +8M -delete
+# configs[3]: dense fp32 MFMA propagation under the same profiler
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dense_trace -- python3 $ROOT/tools/dense_bench.py 10003 5 > $OUT/dense_bench.txt 2> $OUT/dense_trace.err || { tail -5 $OUT/dense_trace.err; exit 1; }
+cat $OUT/dense_bench.txt
+cat $OUT/dense_trace/*/*kernel_stats.csv
