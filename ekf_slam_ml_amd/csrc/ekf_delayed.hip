@@ -172,6 +172,47 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
 // V values are per lane and come from L2 (count x 16 KB per filter).  2*8*N^2 bytes, 2*count*N^2 flop.
 // ---------------------------------------------------------------------------------------------
 template <int U_ROWS, bool NT>
+__device__ __forceinline__ void flush_load(double2_t (&a)[U_ROWS], const double2_t* col, int r, int ld2n) {
+#pragma unroll
+    for (int u = 0; u < U_ROWS; u++) {
+        if constexpr (NT) a[u] = __builtin_nontemporal_load(col + (size_t)(r + u) * ld2n);
+        else a[u] = col[(size_t)(r + u) * ld2n];
+    }
+}
+template <int U_ROWS, bool NT>
+__device__ __forceinline__ void flush_store(const double2_t (&a)[U_ROWS], double2_t* col, int r, int ld2n) {
+#pragma unroll
+    for (int u = 0; u < U_ROWS; u++) {
+        if constexpr (NT) __builtin_nontemporal_store(a[u], col + (size_t)(r + u) * ld2n);
+        else col[(size_t)(r + u) * ld2n] = a[u];
+    }
+}
+// a(u) -= sum over pending pairs of U[j](r+u) V[j](c): 4 * U_ROWS v_fma_f64 per pair, U as scalar operands
+template <int U_ROWS>
+__device__ __forceinline__ void flush_apply(double2_t (&a)[U_ROWS], const double* __restrict__ Ub,
+                                            const double2_t* __restrict__ Vb, int r, int ld, int ld2n, int count) {
+    double2_t v0 = Vb[0], v1 = Vb[ld2n];
+    for (int j = 0; j < count; j += 2) {
+        // V of the NEXT pair is requested before this pair's FMAs (the last trip re-reads pair 0)
+        const int jn = j + 2 < count ? j + 2 : 0;
+        const double2_t v0n = Vb[(size_t)jn * ld2n], v1n = Vb[(size_t)(jn + 1) * ld2n];
+        const double* __restrict__ u0 = Ub + (size_t)j * ld + r;  // wave-uniform -> scalar loads
+        const double* __restrict__ u1 = u0 + ld;
+#pragma unroll
+        for (int u = 0; u < U_ROWS; u++) {
+            const double k0 = -u0[u], k1 = -u1[u];
+            a[u].x = __builtin_fma(k1, v1.x, __builtin_fma(k0, v0.x, a[u].x));
+            a[u].y = __builtin_fma(k1, v1.y, __builtin_fma(k0, v0.y, a[u].y));
+        }
+        v0 = v0n;
+        v1 = v1n;
+    }
+}
+
+// One U_ROWS-row group at a time at 4 waves/SIMD: measured faster than loading two groups up front
+// (206 VGPRs, 2 waves/SIMD): beyond ~16 pending corrections the kernel is bound by fp64 FMA issue
+// (tools/flush_sweep.py), and wave-level parallelism hides the group loads better than a deeper pipeline.
+template <int U_ROWS, bool NT>
 __global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const double* __restrict__ Uall,
                                                const double* __restrict__ Vall, int N, int ld, size_t sigma_stride,
                                                int cap, int count, int rows_per_block) {
@@ -188,42 +229,15 @@ __global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const
     int r = row_begin;
     for (; r + U_ROWS <= row_end; r += U_ROWS) {
         double2_t a[U_ROWS];
-#pragma unroll
-        for (int u = 0; u < U_ROWS; u++) {
-            if constexpr (NT) a[u] = __builtin_nontemporal_load(col + (size_t)(r + u) * ld2n);
-            else a[u] = col[(size_t)(r + u) * ld2n];
-        }
-        double2_t v0 = Vb[0], v1 = Vb[ld2n];
-        for (int j = 0; j < count; j += 2) {
-            // V of the NEXT pair is requested before this pair's FMAs (the last trip re-reads pair 0)
-            const int jn = j + 2 < count ? j + 2 : 0;
-            const double2_t v0n = Vb[(size_t)jn * ld2n], v1n = Vb[(size_t)(jn + 1) * ld2n];
-            const double* __restrict__ u0 = Ub + (size_t)j * ld + r;  // wave-uniform -> scalar loads
-            const double* __restrict__ u1 = u0 + ld;
-#pragma unroll
-            for (int u = 0; u < U_ROWS; u++) {
-                const double k0 = -u0[u], k1 = -u1[u];
-                a[u].x = __builtin_fma(k1, v1.x, __builtin_fma(k0, v0.x, a[u].x));
-                a[u].y = __builtin_fma(k1, v1.y, __builtin_fma(k0, v0.y, a[u].y));
-            }
-            v0 = v0n;
-            v1 = v1n;
-        }
-#pragma unroll
-        for (int u = 0; u < U_ROWS; u++) {
-            if constexpr (NT) __builtin_nontemporal_store(a[u], col + (size_t)(r + u) * ld2n);
-            else col[(size_t)(r + u) * ld2n] = a[u];
-        }
+        flush_load<U_ROWS, NT>(a, col, r, ld2n);
+        flush_apply<U_ROWS>(a, Ub, Vb, r, ld, ld2n, count);
+        flush_store<U_ROWS, NT>(a, col, r, ld2n);
     }
     for (; r < row_end; r++) {
-        double2_t a = col[(size_t)r * ld2n];
-        for (int j = 0; j < count; j += 2) {
-            const double2_t v0 = Vb[(size_t)j * ld2n], v1 = Vb[(size_t)(j + 1) * ld2n];
-            const double k0 = Ub[(size_t)j * ld + r], k1 = Ub[(size_t)(j + 1) * ld + r];
-            a.x = a.x - (k0 * v0.x + k1 * v1.x);
-            a.y = a.y - (k0 * v0.y + k1 * v1.y);
-        }
-        col[(size_t)r * ld2n] = a;
+        double2_t a[1];
+        flush_load<1, false>(a, col, r, ld2n);
+        flush_apply<1>(a, Ub, Vb, r, ld, ld2n, count);
+        flush_store<1, false>(a, col, r, ld2n);
     }
 }
 
