@@ -35,6 +35,7 @@ SYMBOLS = [
     "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_get_state", "ekf_batch_get_cov",
     "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
     "ekf_set_update_mode", "ekf_batch_set_update_mode",
+    "ekf_circle_fit_scans",
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
 ]
 
@@ -115,6 +116,7 @@ def load():
         "ekf_batch_set_tuning": [h, C.c_int, C.c_int, C.c_int],
         "ekf_set_update_mode": [h, C.c_int],
         "ekf_batch_set_update_mode": [h, C.c_int],
+        "ekf_circle_fit_scans": [C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _ip, _dp, _ip],
         "ekf_dense_create": [C.c_int, C.c_int, C.POINTER(h)],
         "ekf_dense_destroy": [h],
         "ekf_dense_set": [h, _fp, _fp, _fp],
@@ -385,3 +387,28 @@ class DensePropagator:
         out = np.empty((self.N, self.N), dtype=np.float32)
         _check(self._lib.ekf_dense_get_sigma(self._h, out.ctypes.data_as(_fp)))
         return out
+
+
+MAX_CLUSTERS = 128
+
+
+def circle_fit_scans(ranges, max_out=32, device=-1, want_all=False):
+    """Batched rigid2d::CircleFitting::approxCirclePositions (circle_fitting.cpp:298-304) on the GPU.
+    ranges [S, n_beams] -> list of per-scan centre arrays [k_s, 2] and radii [k_s]
+    (+ per-scan [c_s, 4] = x, y, r, is_circle of every cluster when want_all)."""
+    r = np.ascontiguousarray(ranges, dtype=np.float64)
+    if r.ndim == 1:
+        r = r[None, :]
+    S, nb = r.shape
+    cen = np.zeros((S, max_out, 2))
+    rad = np.zeros((S, max_out))
+    cnt = np.zeros(S, dtype=np.int32)
+    ncl = np.zeros(S, dtype=np.int32)
+    allc = np.zeros((S, MAX_CLUSTERS, 4)) if want_all else None
+    _check(load().ekf_circle_fit_scans(device, _d(r), S, nb, max_out, _d(cen), _d(rad), cnt.ctypes.data_as(_ip),
+                                       _d(allc) if want_all else None, ncl.ctypes.data_as(_ip)))
+    centres = [cen[s, :cnt[s]].copy() for s in range(S)]
+    radii = [rad[s, :cnt[s]].copy() for s in range(S)]
+    if want_all:
+        return centres, radii, [allc[s, :ncl[s]].copy() for s in range(S)]
+    return centres, radii

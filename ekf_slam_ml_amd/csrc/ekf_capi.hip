@@ -407,15 +407,22 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     EKFC(P.use());
     const int n = P.pv.n;
     EKFC(P.upload(P.sensor_dev, sensor_xy, sizeof(double) * 2 * n));
-    ekf::launch_measure_begin(P.pv, P.sensor_dev, !P.init_flag, P.stream);  // ekf_slam.cpp:109-128
+    // ekf_slam.cpp:109-128.  The pose capture needs its own launch only together with the first-call
+    // landmark initialisation; afterwards the first correction of the call records the pose it reads
+    // (no correction has moved it yet) and the later ones use that record.
+    const bool need_begin = !P.init_flag;
+    if (need_begin) ekf::launch_measure_begin(P.pv, P.sensor_dev, 1, P.stream);
     P.init_flag = 1;
     ekf::CmdSrc src{};
     src.mode = ekf::SRC_SENSOR_VECTOR;
     src.sensor = P.sensor_dev;
-    src.fresh_pose = 0;
+    bool first = !need_begin;
     for (int i = 0; i < n; i++) {  // ekf_slam.cpp:132-194, ascending landmark order
         if (!visible[i]) continue;
         src.lm_imm = i;
+        src.fresh_pose = first ? 1 : 0;
+        src.write_snap = first ? 1 : 0;
+        first = false;
         EKFC(P.correct(src));
     }
     return checked_launch();
@@ -736,6 +743,50 @@ ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]) {
     for (int b = 0; b < P.pv.B; b++)
         for (int k = 0; k < 4; k++) out[k] += h[(size_t)b * 4 + k];
     return EKF_OK;
+}
+
+// ---- laser-scan front end (f3) -------------------------------------------------------------------
+
+ekf_status ekf_circle_fit_scans(int device, const double* ranges, int S, int n_beams, int max_out, double* centres,
+                                double* radii, int* counts, double* all_clusters, int* n_clusters) {
+    if (!ranges || !centres || !radii || !counts || S < 0 || n_beams < 1 || max_out < 1 ||
+        n_beams > ekf::circles_max_beams())
+        return fail(EKF_ERR_INVALID, "ekf_circle_fit_scans: bad argument (n_beams must be 1..1024)");
+    if (S == 0) return EKF_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(EKF_ERR_NO_DEVICE, "no HIP device visible: libekfslam_hip has no CPU path");
+    if (device < 0) HIPC(hipGetDevice(&device));
+    if (device >= count) return fail(EKF_ERR_INVALID, "device index out of range");
+    HIPC(hipSetDevice(device));
+    const int mc = ekf::circles_max_clusters();
+    double *d_r = nullptr, *d_c = nullptr, *d_rad = nullptr, *d_all = nullptr;
+    int *d_cnt = nullptr, *d_nc = nullptr;
+    ekf_status st = EKF_OK;
+    auto body = [&]() -> ekf_status {
+        HIPC(hipMalloc((void**)&d_r, sizeof(double) * (size_t)S * n_beams));
+        HIPC(hipMalloc((void**)&d_c, sizeof(double) * (size_t)S * max_out * 2));
+        HIPC(hipMalloc((void**)&d_rad, sizeof(double) * (size_t)S * max_out));
+        HIPC(hipMalloc((void**)&d_cnt, sizeof(int) * (size_t)S));
+        HIPC(hipMalloc((void**)&d_nc, sizeof(int) * (size_t)S));
+        if (all_clusters) HIPC(hipMalloc((void**)&d_all, sizeof(double) * (size_t)S * mc * 4));
+        HIPC(hipMemcpy(d_r, ranges, sizeof(double) * (size_t)S * n_beams, hipMemcpyHostToDevice));
+        HIPC(hipMemset(d_c, 0, sizeof(double) * (size_t)S * max_out * 2));
+        HIPC(hipMemset(d_rad, 0, sizeof(double) * (size_t)S * max_out));
+        if (d_all) HIPC(hipMemset(d_all, 0, sizeof(double) * (size_t)S * mc * 4));
+        ekf::launch_circles(d_r, S, n_beams, max_out, d_c, d_rad, d_cnt, d_all, d_nc, nullptr);
+        HIPC(hipGetLastError());
+        HIPC(hipMemcpy(centres, d_c, sizeof(double) * (size_t)S * max_out * 2, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(radii, d_rad, sizeof(double) * (size_t)S * max_out, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(counts, d_cnt, sizeof(int) * (size_t)S, hipMemcpyDeviceToHost));
+        if (n_clusters) HIPC(hipMemcpy(n_clusters, d_nc, sizeof(int) * (size_t)S, hipMemcpyDeviceToHost));
+        if (all_clusters) HIPC(hipMemcpy(all_clusters, d_all, sizeof(double) * (size_t)S * mc * 4, hipMemcpyDeviceToHost));
+        return EKF_OK;
+    };
+    st = body();
+    for (void* p : {(void*)d_r, (void*)d_c, (void*)d_rad, (void*)d_cnt, (void*)d_nc, (void*)d_all})
+        if (p) (void)hipFree(p);
+    return st;
 }
 
 // ---- dense fp32 propagation (configs[3]) -----------------------------------------------------

@@ -92,6 +92,10 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
             const double* sn = pv.snap + (size_t)b * 4;
             theta = sn[0]; x = sn[1]; y = sn[2];
         }
+        if (src.write_snap && blockIdx.x == 0) {
+            double* sn = pv.snap + (size_t)b * 4;
+            sn[0] = theta; sn[1] = x; sn[2] = y;
+        }
         MeasTerms m;
         measurement_terms(st[2 * lm + 3], st[2 * lm + 4], sx, sy, theta, x, y, m);
         double S55[5][5], S[2][2], Si[2][2];

@@ -132,14 +132,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
         if (kt + 1 < nk) gload((kt + 1) * BK);  // next tile's global loads fly under this tile's MFMAs
         const float* as = smem + cur * BUF_ELEMS + wm * 64 + li;
         const float* bs = smem + cur * BUF_ELEMS + A_ELEMS + wn * 64 + li;
+        // fragments of k-step kk+2 are read from LDS before the four MFMAs of k-step kk are issued, so the
+        // ds_read latency hides under 4 x 64 cycles of matrix work instead of stalling in front of them
+        float a0 = as[lk * SA], a1 = as[lk * SA + 32];
+        float b0 = bs[lk * SB], b1 = bs[lk * SB + 32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = as[(kk + lk) * SA], a1 = as[(kk + lk) * SA + 32];
-            const float b0 = bs[(kk + lk) * SB], b1 = bs[(kk + lk) * SB + 32];
+            float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
+            if (kk + 2 < BK) {
+                a0n = as[(kk + 2 + lk) * SA]; a1n = as[(kk + 2 + lk) * SA + 32];
+                b0n = bs[(kk + 2 + lk) * SB]; b1n = bs[(kk + 2 + lk) * SB + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep hipcc from sinking the reads back below the MFMAs
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
         }
         if (kt + 1 < nk) {
             lstore(cur ^ 1);  // the other buffer was last read one barrier ago

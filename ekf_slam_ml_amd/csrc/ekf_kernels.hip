@@ -64,6 +64,30 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
     const double dtheta = twist_dev ? twist_dev[(size_t)b * 2 + 0] : dth_imm;  // twist.angular()  :67
     const double dx = twist_dev ? twist_dev[(size_t)b * 2 + 1] : dx_imm;       // twist.linearX()  :69
     const double theta = st[0];
+
+    // Latency matters here (one workgroup per filter, a 10 Hz node calls this on a single filter): the
+    // covariance entries do not depend on theta, so the first two trips' loads are issued before the
+    // trigonometry and fly under it.
+    constexpr int PRE = 2;
+    double s0[PRE], s1[PRE], s2[PRE], r0[PRE], r1[PRE], r2[PRE];
+#pragma unroll
+    for (int q = 0; q < PRE; q++) {
+        const int k = 3 + (int)threadIdx.x + q * kPredictThreads;
+        if (k < N) {
+            s0[q] = Sg[k];                      // row 0 (coalesced)
+            s1[q] = Sg[(size_t)1 * ld + k];
+            s2[q] = Sg[(size_t)2 * ld + k];
+            const double* rowk = Sg + (size_t)k * ld;  // columns 0..2 of row k (one 32-B sector)
+            r0[q] = rowk[0]; r1[q] = rowk[1]; r2[q] = rowk[2];
+        }
+    }
+    double c[3][3], px = 0.0, py = 0.0;
+    if (threadIdx.x == 0) {
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) c[r][k] = Sg[(size_t)r * ld + k];
+        px = st[1]; py = st[2];
+    }
+
     double u0, u1, u2, a10, a20;
     if (fabs(dtheta) < pv.p.straight_eps) {  // :79-86
         u0 = 0;
@@ -80,16 +104,27 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
     }
     __syncthreads();  // all threads hold the old theta; thread 0 may now move the pose
 
-    for (int k = 3 + threadIdx.x; k < N; k += kPredictThreads) {
-        const double s0 = Sg[k];                      // row 0 (coalesced)
-        const double s1 = Sg[(size_t)1 * ld + k];
-        const double s2 = Sg[(size_t)2 * ld + k];
-        double* rowk = Sg + (size_t)k * ld;           // columns 0..2 of row k (one 32-B sector)
-        const double r0 = rowk[0], r1 = rowk[1], r2 = rowk[2];
-        Sg[(size_t)1 * ld + k] = a10 * s0 + s1;
-        Sg[(size_t)2 * ld + k] = a20 * s0 + s2;
-        rowk[1] = r0 * a10 + r1;
-        rowk[2] = r0 * a20 + r2;
+#pragma unroll
+    for (int q = 0; q < PRE; q++) {
+        const int k = 3 + (int)threadIdx.x + q * kPredictThreads;
+        if (k < N) {
+            double* rowk = Sg + (size_t)k * ld;
+            Sg[(size_t)1 * ld + k] = a10 * s0[q] + s1[q];
+            Sg[(size_t)2 * ld + k] = a20 * s0[q] + s2[q];
+            rowk[1] = r0[q] * a10 + r1[q];
+            rowk[2] = r0[q] * a20 + r2[q];
+        }
+    }
+    for (int k = 3 + threadIdx.x + PRE * kPredictThreads; k < N; k += kPredictThreads) {
+        const double t0 = Sg[k];
+        const double t1 = Sg[(size_t)1 * ld + k];
+        const double t2 = Sg[(size_t)2 * ld + k];
+        double* rowk = Sg + (size_t)k * ld;
+        const double q0 = rowk[0], q1 = rowk[1], q2 = rowk[2];
+        Sg[(size_t)1 * ld + k] = a10 * t0 + t1;
+        Sg[(size_t)2 * ld + k] = a20 * t0 + t2;
+        rowk[1] = q0 * a10 + q1;
+        rowk[2] = q0 * a20 + q2;
     }
     // Delayed-update mode: Sigma = Sigma_base - sum_j u_j v_j^T with pending factors; At (.) At^T maps the
     // base (above) and every factor: u <- At u, v <- At v (only entries 1 and 2 change).
@@ -104,11 +139,9 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
     }
     if (threadIdx.x == 0) {
         st[0] = theta + u0;  // :99 -- theta is NOT wrapped after the prediction
-        st[1] = st[1] + u1;
-        st[2] = st[2] + u2;
-        double c[3][3], T[3][3];
-        for (int r = 0; r < 3; r++)
-            for (int k = 0; k < 3; k++) c[r][k] = Sg[(size_t)r * ld + k];
+        st[1] = px + u1;
+        st[2] = py + u2;
+        double T[3][3];
         for (int k = 0; k < 3; k++) {
             T[0][k] = c[0][k];
             T[1][k] = a10 * c[0][k] + c[1][k];
@@ -195,18 +228,39 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
 
     const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
     const double* st = pv.state + (size_t)b * ld;
+    // Everything this workgroup reads depends only on lm, so all loads are issued up front and fly
+    // together (latency matters for a single filter): the lane's 5 column + 5 row entries, the 5x5
+    // block, and -- on lane 0 -- the pose and the landmark.
+    const int r = blockIdx.x * 256 + tid;
+    double p[5], g[5];
+    if (r < N) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int c = idx5(k, lm);
+            p[k] = Sg[(size_t)r * ld + c];  // column gather (Sigma * H^T reads columns)
+            g[k] = Sg[(size_t)c * ld + r];  // row gather    (H * Sigma reads rows)
+        }
+    }
     if (tid < 25) sh_S55[tid] = Sg[(size_t)idx5(tid / 5, lm) * ld + idx5(tid % 5, lm)];
-    __syncthreads();
+    double theta = 0.0, x = 0.0, y = 0.0, tx = 0.0, ty = 0.0;
     if (tid == 0) {
-        double theta, x, y;
         if (src.fresh_pose) {  // data_association re-reads the pose per measurement, :331-333
             theta = st[0]; x = st[1]; y = st[2];
         } else {               // measurement() keeps the pose captured at :109-111
             const double* sn = pv.snap + (size_t)b * 4;
             theta = sn[0]; x = sn[1]; y = sn[2];
         }
+        tx = st[2 * lm + 3];
+        ty = st[2 * lm + 4];
+        if (src.write_snap && blockIdx.x == 0) {
+            double* sn = pv.snap + (size_t)b * 4;
+            sn[0] = theta; sn[1] = x; sn[2] = y;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
         MeasTerms m;
-        measurement_terms(st[2 * lm + 3], st[2 * lm + 4], sx, sy, theta, x, y, m);
+        measurement_terms(tx, ty, sx, sy, theta, x, y, m);
         double S55[5][5], S[2][2], Si[2][2];
         for (int k = 0; k < 5; k++)
             for (int l = 0; l < 5; l++) S55[k][l] = sh_S55[k * 5 + l];
@@ -216,30 +270,26 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
             for (int k = 0; k < 5; k++) sh_H[a * 5 + k] = m.H[a][k];
         sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
         if (blockIdx.x == 0) {
-            CorrRec r;
-            r.nu0 = m.z0 - m.zh0;                    // :182
-            r.nu1 = normalize_angle(m.z1 - m.zh1);   // :183
-            r.active = 1;
-            r.lm = lm;
-            pv.rec[b] = r;
+            CorrRec rc;
+            rc.nu0 = m.z0 - m.zh0;                    // :182
+            rc.nu1 = normalize_angle(m.z1 - m.zh1);   // :183
+            rc.active = 1;
+            rc.lm = lm;
+            pv.rec[b] = rc;
         }
     }
     __syncthreads();
 
-    const int r = blockIdx.x * 256 + tid;
     if (r >= ld) return;
     double k0 = 0.0, k1 = 0.0, g0 = 0.0, g1 = 0.0;
     if (r < N) {
         double sht0 = 0.0, sht1 = 0.0;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            const int c = idx5(k, lm);
-            const double p = Sg[(size_t)r * ld + c];  // column gather (Sigma * H^T reads columns)
-            const double g = Sg[(size_t)c * ld + r];  // row gather    (H * Sigma reads rows)
-            sht0 += p * sh_H[k];
-            sht1 += p * sh_H[5 + k];
-            g0 += sh_H[k] * g;
-            g1 += sh_H[5 + k] * g;
+            sht0 += p[k] * sh_H[k];
+            sht1 += p[k] * sh_H[5 + k];
+            g0 += sh_H[k] * g[k];
+            g1 += sh_H[5 + k] * g[k];
         }
         k0 = sht0 * sh_Si[0] + sht1 * sh_Si[2];  // K = (Sigma H^T) S^-1   :178
         k1 = sht0 * sh_Si[1] + sht1 * sh_Si[3];

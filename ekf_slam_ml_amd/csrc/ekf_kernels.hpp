@@ -71,6 +71,8 @@ struct CmdSrc {
     const AssocRec* assoc;  // SRC_ASSOC: per-filter decision
     const double* meas;     // SRC_ASSOC: [B][2] current measurement
     int fresh_pose;         // 1: read (theta,x,y) from state (:331-333); 0: from snap (:109-111)
+    int write_snap;         // 1: this is the first correction of a measurement() call -- its fresh pose IS
+                            //    the pose captured at :109-111; record it in snap for the corrections after it
 };
 
 struct PoolView {
@@ -177,6 +179,12 @@ void launch_assoc_decide(const PoolView& pv, const double* meas, const double* s
                          int out_stride, int j, hipStream_t s);
 // out[b][4] += {sum state, sum |state|, sum sigma, sum |sigma|}; caller zeroes out first
 void launch_checksum(const PoolView& pv, double* out, hipStream_t s);
+// batched rigid2d::CircleFitting::approxCirclePositions (ekf_circles.hip): S scans of nb beams ->
+// centres [S][max_out][2], radii [S][max_out], counts [S]; all_out (nullable) [S][circles_max_clusters()][4]
+void launch_circles(const double* ranges, int S, int nb, int max_out, double* centres, double* radii, int* counts,
+                    double* all_out, int* n_clusters, hipStream_t s);
+int circles_max_beams();
+int circles_max_clusters();
 int max_pending();  // capacity limit of the delayed-update factor store (rows of U / V per filter)
 void launch_gather_poses(const PoolView& pv, double* out, hipStream_t s);
 

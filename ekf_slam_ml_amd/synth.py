@@ -332,3 +332,41 @@ def config5(filters=4096, steps=20, first_filter_id=0, n=1000):
     return SimConfig(n=n, steps=steps, filters=filters, seed=5_000_000, first_filter_id=first_filter_id,
                      half_extent=12.0, min_spacing=0.6, v_cmd=0.5, w_cmd=0.06,
                      max_visible_dis=1.0e9, vmax=2, world_seed=5)
+
+
+# ---- simulated 360-beam laser scans (input of the circle-fitting front end) --------
+# tube_world.cpp:454-577 (publishScan): beam i at angle 2*pi*i/360 in the robot frame, nearest hit of the
+# square world border (world_border_width 2.0, tube_param.yaml:5) or of a tube (radius 0.0762,
+# tube_param.yaml:4), capped at range_max 3.5, plus N(0, range_std = 0.005) (noise_param.yaml:11).
+TUBE_RADIUS = 0.0762
+WORLD_BORDER_WIDTH = 2.0
+KIND_SCAN = 6
+
+
+def make_scans(poses, world=None, n_beams=360, seed=7, range_std=0.005, range_max=3.5,
+               border=WORLD_BORDER_WIDTH, tube_radius=TUBE_RADIUS):
+    """poses [S, 3] = (theta, x, y) -> ranges [S, n_beams] (float64), deterministic in (seed, scan id, beam)."""
+    poses = np.asarray(poses, dtype=np.float64).reshape(-1, 3)
+    if world is None:
+        world = np.stack([TUBE_X, TUBE_Y], axis=1)
+    S = len(poses)
+    ang = 2.0 * np.pi * np.arange(n_beams) / n_beams
+    th = poses[:, 0:1] + ang[None, :]                       # world-frame beam direction [S, nb]
+    dx, dy = np.cos(th), np.sin(th)
+    ox, oy = poses[:, 1:2], poses[:, 2:3]
+    half = border / 2.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tx = np.where(dx > 0, (half - ox) / dx, np.where(dx < 0, (-half - ox) / dx, np.inf))
+        ty = np.where(dy > 0, (half - oy) / dy, np.where(dy < 0, (-half - oy) / dy, np.inf))
+    r = np.minimum(np.minimum(tx, ty), range_max)
+    for (cx, cy) in world:                                  # ray-circle intersection, nearest root
+        fx, fy = ox - cx, oy - cy
+        bq = fx * dx + fy * dy
+        cq = fx * fx + fy * fy - tube_radius ** 2
+        disc = bq * bq - cq
+        hit = disc > 0
+        t = -bq - np.sqrt(np.where(hit, disc, 0.0))
+        r = np.where(hit & (t > 0) & (t < r), t, r)
+    sid = np.arange(S, dtype=np.uint64)[:, None]
+    noise = range_std * normal01(seed, sid, 0, KIND_SCAN, np.arange(n_beams, dtype=np.uint64)[None, :])
+    return r + noise

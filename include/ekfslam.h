@@ -176,6 +176,19 @@ ekf_status ekf_dense_set(ekf_dense_handle h, const float* F, const float* Sigma,
 ekf_status ekf_dense_propagate(ekf_dense_handle h, int iterations, double* elapsed_ms);
 ekf_status ekf_dense_get_sigma(ekf_dense_handle h, float* out);
 
+/* ---- laser-scan front end: rigid2d::CircleFitting, batched ----------
+ * std::vector<Vector2D> approxCirclePositions(std::vector<double> ranges)
+ *                                          circle_fitting.hpp:27, circle_fitting.cpp:298-304
+ * = clusteringRanges (:11-90) + circleRegression (:104-232) + classifyCircle (:234-296): the producer
+ * of the `measures` argument of data_association (nuslam/src/landmarks.cpp:141 ->
+ * unknown_data_assoc.cpp:309-320).  S scans of n_beams ranges each (beam i at angle 2*pi*i/n_beams):
+ *   centres [S][max_out][2], radii [S][max_out], counts [S] (circles kept per scan, <= max_out);
+ *   all_clusters (nullable) [S][128][4] = {x, y, r, is_circle} of EVERY cluster, n_clusters (nullable) [S].
+ * n_beams <= 1024.  A scan without any cluster (undefined behaviour in the reference, :54) gives 0. */
+ekf_status ekf_circle_fit_scans(int device, const double* ranges, int S, int n_beams, int max_out,
+                                double* centres, double* radii, int* counts, double* all_clusters,
+                                int* n_clusters);
+
 #ifdef __cplusplus
 }
 #endif

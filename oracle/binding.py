@@ -15,8 +15,9 @@ _bp = C.POINTER(C.c_ubyte)
 
 def build(force=False):
     """Compile the checker (and oracle/_ref when /root/reference is present)."""
-    if force or not os.path.exists(os.path.join(_HERE, "libekf_oracle.so")) \
-            or os.path.getmtime(os.path.join(_HERE, "libekf_oracle.so")) < os.path.getmtime(os.path.join(_HERE, "ekf_oracle.c")):
+    so = os.path.join(_HERE, "libekf_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("ekf_oracle.c", "circle_oracle.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-s", "all"], check=True)
 
 
@@ -57,6 +58,13 @@ def _load(fast=False):
     lib.ekfo_get_init_flag.argtypes = [C.c_void_p]
     lib.ekfo_batch_run_known.restype = C.c_int
     lib.ekfo_batch_run_known.argtypes = [C.c_int] * 6 + [_dp, _ip, _dp, _dp, _dp, _dp, C.c_int, _dp]
+    lib.cf_regress.argtypes = [_dp, _dp, C.c_int, _dp]
+    lib.cf_is_circle.restype = C.c_int
+    lib.cf_is_circle.argtypes = [_dp, _dp, C.c_int, C.c_double]
+    lib.cf_approx_circle_positions.restype = C.c_int
+    lib.cf_approx_circle_positions.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, _dp, _ip]
+    lib.cf_cluster_summary.restype = C.c_int
+    lib.cf_cluster_summary.argtypes = [_dp, C.c_int, C.c_int, _ip, _dp]
     return lib
 
 
@@ -206,3 +214,32 @@ class RefRigid2D:
 
     def update_pose(self, wb, wr, left, right):
         return self._call3("ref_update_pose", wb, wr, left, right)
+
+
+# ---- rigid2d::CircleFitting (oracle/circle_oracle.c) -------------------------------------------------
+
+def circle_regress(xy):
+    """circleRegression() for one cluster of (x, y) points -> (cx, cy, r); circle_fitting.cpp:104-232."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+    xs, ys = np.ascontiguousarray(xy[:, 0]), np.ascontiguousarray(xy[:, 1])
+    out = np.zeros(3)
+    lib().cf_regress(_d(xs), _d(ys), len(xs), _d(out))
+    return out
+
+
+def circle_clusters(ranges):
+    """clusteringRanges(): (sizes, first range of each cluster); circle_fitting.cpp:11-90."""
+    r = np.ascontiguousarray(ranges, dtype=np.float64)
+    sizes = np.zeros(300, dtype=np.int32)
+    first = np.zeros(300)
+    nc = lib().cf_cluster_summary(_d(r), len(r), 300, sizes.ctypes.data_as(_ip), _d(first))
+    return sizes[:nc].copy(), first[:nc].copy()
+
+
+def approx_circle_positions(ranges, max_out=64):
+    """approxCirclePositions(): (clean centres [k,2], clean radii [k], all clusters [c,4] = x,y,r,is_circle)."""
+    r = np.ascontiguousarray(ranges, dtype=np.float64)
+    xy, rad, allc = np.zeros((max_out, 2)), np.zeros(max_out), np.zeros((300, 4))
+    nc = C.c_int()
+    k = lib().cf_approx_circle_positions(_d(r), len(r), max_out, _d(xy), _d(rad), _d(allc), C.byref(nc))
+    return xy[:k].copy(), rad[:k].copy(), allc[:nc.value].copy()

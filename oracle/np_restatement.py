@@ -127,3 +127,91 @@ class NumpyEKF:
             else:
                 assoc.append(-1)
         return np.array(assoc, dtype=np.int32)
+
+
+# ---- rigid2d::CircleFitting, literal LAPACK-backed transcription (second opinion) ---------------------
+
+def np_cluster(ranges):
+    """circle_fitting.cpp:11-90 -> list of clusters, each a list of beam indices."""
+    n = len(ranges)
+    thres = 0.2
+    clusters, cur = [], [0]
+    for i in range(1, n):
+        if abs(ranges[i] - ranges[i - 1]) < thres and i != n - 1:
+            pass
+        else:
+            if len(cur) > 6:
+                clusters.append(cur)
+            cur = []
+        cur.append(i)
+    if not clusters:
+        return []                      # the reference indexes an empty vector here (UB)
+    if abs(ranges[clusters[0][0]] - ranges[clusters[-1][-1]]) < thres:
+        last = clusters[-1]
+        clusters[0] = list(last) + clusters[0]   # :63-66 (a single cluster is prepended to itself ...)
+        clusters.pop()                          # :68-69 (... and popped)
+    return clusters
+
+
+def np_beam_xy(ranges, i):
+    n = len(ranges)
+    res = 2 * PI / n
+    if i == 0:
+        return ranges[0] * math.cos(0.0), ranges[0] * math.sin(0.0)
+    a = normalize_angle(i * res)
+    return ranges[i] * math.cos(a), ranges[i] * math.sin(a)
+
+
+def np_circle_regress(xy):
+    """circle_fitting.cpp:104-232 with numpy.linalg.svd / eig / solve -> (cx, cy, r)."""
+    xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+    m = len(xy)
+    x_mean, y_mean = xy[:, 0].sum() / m, xy[:, 1].sum() / m
+    x, y = xy[:, 0] - x_mean, xy[:, 1] - y_mean
+    z = x ** 2 + y ** 2
+    z_mean = z.sum() / m
+    Z = np.stack([z, x, y, np.ones(m)], axis=1)
+    H_inv = np.zeros((4, 4))
+    H_inv[0, 3] = 0.5; H_inv[1, 1] = 1.0; H_inv[2, 2] = 1.0; H_inv[3, 0] = 0.5; H_inv[3, 3] = -2.0 * z_mean
+    _, s, Vt = np.linalg.svd(Z, full_matrices=True)
+    V = Vt.T
+    if s[3] < 1e-12:
+        A = V[:, 3]
+    else:
+        Y = V @ np.diag(s) @ V.T
+        Q = Y @ H_inv @ Y
+        w, E = np.linalg.eig(Q)
+        idx, best = 0, 1000.0
+        for e in range(4):
+            if w[e].real > 0 and w[e].real < best:
+                best, idx = w[e].real, e
+        A = np.linalg.solve(Y, E[:, idx].real)
+    a = -A[1] / (2 * A[0])
+    b = -A[2] / (2 * A[0])
+    R_sqr = (A[1] ** 2 + A[2] ** 2 - 4 * A[0] * A[3]) / (4 * A[0] ** 2)
+    return np.array([a + x_mean, b + y_mean, math.sqrt(R_sqr)])
+
+
+def np_is_circle(xy, radius):
+    """circle_fitting.cpp:234-296."""
+    xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+    p1, p2 = xy[0], xy[-1]
+    s = 0.0
+    for k in range(1, len(xy) - 1):
+        a, b = p1 - xy[k], p2 - xy[k]
+        s += math.acos((a[0] * b[0] + a[1] * b[1]) / (math.hypot(a[0], a[1]) * math.hypot(b[0], b[1])))
+    mean = s / (len(xy) - 2)
+    return mean > 1.5708 and mean < 2.3562 and radius < 0.2
+
+
+def np_approx_circle_positions(ranges):
+    """circle_fitting.cpp:298-304 -> (clean centres, all clusters [x, y, r, is_circle])."""
+    out, clean = [], []
+    for cl in np_cluster(list(ranges)):
+        xy = np.array([np_beam_xy(ranges, i) for i in cl])
+        cx, cy, r = np_circle_regress(xy)
+        ok = np_is_circle(xy, r)
+        out.append([cx, cy, r, float(ok)])
+        if ok:
+            clean.append([cx, cy])
+    return np.array(clean).reshape(-1, 2), np.array(out).reshape(-1, 4)

@@ -4,22 +4,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ekf_slam_ml_amd import capi, synth
 
-def known(n_steps=400):
-    log = synth.make_known_log(synth.config2(steps=n_steps))
-    f = capi.EKF_SLAM(200)
+
+def known(n, cfg, n_steps, modes=(0, 8, 16, 32)):
+    log = synth.make_known_log(cfg)
     steps = [log.expand_step(t) for t in range(n_steps)]
-    for t in range(50):
-        f.prediction(log.twist[t, 0]); f.measurement(*steps[t])
-    f.sync()
-    t0 = time.perf_counter()
-    for t in range(50, n_steps):
-        f.prediction(log.twist[t, 0]); f.measurement(*steps[t])
-    f.sync()
-    dt = time.perf_counter() - t0
-    corr = int((log.lm_idx[50:] >= 0).sum())
-    print(f"configs[1] n=200 known: {(n_steps-50)/dt:.0f} steps/s, {corr/dt:.0f} corrections/s, {dt/corr*1e6:.1f} us/correction "
-          f"(V~{corr/(n_steps-50):.1f}); alg GB/s {corr*16*403**2/dt/1e9:.1f}", flush=True)
-    f.close()
+    for k in modes:
+        f = capi.EKF_SLAM(n)
+        f.set_update_mode(k)
+        for t in range(20):
+            f.prediction(log.twist[t, 0]); f.measurement(*steps[t])
+        f.sync()
+        t0 = time.perf_counter()
+        for t in range(20, n_steps):
+            f.prediction(log.twist[t, 0]); f.measurement(*steps[t])
+        f.sync()
+        dt = time.perf_counter() - t0
+        corr = int((log.lm_idx[20:] >= 0).sum())
+        N = 3 + 2 * n
+        print(f"n={n} known, update mode k={k:2d}: {(n_steps - 20) / dt:7.0f} steps/s, {corr / dt:8.0f} corrections/s, "
+              f"{dt / corr * 1e6:6.1f} us/correction (V~{corr / (n_steps - 20):.1f}); eager-equivalent alg GB/s {corr * 16 * N * N / dt / 1e9:.0f}", flush=True)
+        f.close()
+
 
 def unknown(n_steps=150):
     log = synth.make_unknown_log(synth.config3(steps=n_steps))
@@ -36,27 +41,11 @@ def unknown(n_steps=150):
         upd += int((a >= 0).sum()); meas += len(a)
     f.sync()
     dt = time.perf_counter() - t0
-    print(f"configs[2] n=1000 unknown: {(n_steps-20)/dt:.0f} steps/s, {meas/dt:.0f} measurements/s, {upd/dt:.0f} corrections/s, "
-          f"{dt/max(upd,1)*1e6:.1f} us/correction, known={int(k.sum())}; alg GB/s {upd*16*2003**2/dt/1e9:.1f}", flush=True)
+    print(f"configs[2] n=1000 unknown: {(n_steps - 20) / dt:.0f} steps/s, {meas / dt:.0f} measurements/s, {upd / dt:.0f} corrections/s, "
+          f"{dt / max(meas, 1) * 1e6:.1f} us/measurement, known={int(k.sum())}", flush=True)
     f.close()
 
-def known1000(n_steps=120):
-    cfg = synth.config3(steps=n_steps); 
-    log = synth.make_known_log(cfg)
-    f = capi.EKF_SLAM(1000)
-    steps = [log.expand_step(t) for t in range(n_steps)]
-    for t in range(20):
-        f.prediction(log.twist[t, 0]); f.measurement(*steps[t])
-    f.sync()
-    for rows, u in ((0, 0), (4, 4), (8, 8), (16, 8), (16, 16), (32, 16)):
-        f.set_tuning(rows, -1, u)
-        t0 = time.perf_counter()
-        for t in range(20, n_steps):
-            f.prediction(log.twist[t, 0]); f.measurement(*steps[t])
-        f.sync()
-        dt = time.perf_counter() - t0
-        corr = int((log.lm_idx[20:] >= 0).sum())
-        print(f"n=1000 known single filter rows={rows} U={u}: {corr/dt:.0f} corrections/s, {dt/corr*1e6:.1f} us/correction; alg GB/s {corr*16*2003**2/dt/1e9:.0f}", flush=True)
-    f.close()
 
-known(); unknown(); known1000()
+known(200, synth.config2(steps=400), 400)
+known(1000, synth.config3(steps=120), 120)
+unknown()
