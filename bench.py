@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--cpu-filters", type=int, default=0)
     ap.add_argument("--delayed-k", type=int, default=32,
                     help="also time the delayed rank-2k update with this many corrections per flush (0 = skip)")
+    ap.add_argument("--host-log", action="store_true",
+                    help="generate the synthetic log on the host (numpy) and upload it, instead of on the device")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
     return ap.parse_args()
@@ -97,10 +99,16 @@ def main():
     first_id, count = shard.shard(B * world, world, rank)  # weak scaling: B filters per GPU, global ids
     assert count == B
     cfg = synth.config5(filters=B, steps=T, first_filter_id=first_id, n=n)
-    log = synth.make_known_log(cfg)
     bt = capi.BatchEKF(B, n, device=local)
     bt.set_tuning(a.rows, a.nt)
-    bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+    if a.host_log:
+        log = synth.make_known_log(cfg)
+        bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+    else:
+        # inputs are generated ON THE DEVICE (same noise model and random-number addressing as synth.py)
+        world_xy = synth.make_world(n, cfg.half_extent, cfg.min_spacing, cfg.world_seed)
+        bt.simulate_known_log(cfg, world_xy)
+        log = None
     bt.run_known(0, 1 + W)  # init step + W untimed warm-up steps
 
     def fence():
@@ -194,6 +202,9 @@ def main():
         }
         if delayed is not None:
             out["delayed_update"] = delayed
+        if not a.host_log:
+            # Monte-Carlo consistency of the batch against the simulated ground truth (f4)
+            out["mc_consistency"] = bt.mc_stats(T - 1)
         if world == 1 and not a.no_cpu_baseline:
             # the box's CPU share for a one-GPU job is 16 cores (the machine reports all 256)
             cores = int(os.environ.get("EKF_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
@@ -202,8 +213,12 @@ def main():
             import copy
             cfg_c = copy.copy(cfg)
             cfg_c.filters = Bc
-            sub = synth.KnownLog(cfg_c, log.world, log.twist[:, :Bc], log.lm_idx[:, :Bc], log.z_xy[:, :Bc],
-                                 log.init_xy[:Bc])
+            if log is None:
+                tw, li, zz, ii, _ = bt.download_log(want_truth=False)
+                sub = synth.KnownLog(cfg_c, world_xy, tw[:, :Bc], li[:, :Bc], zz[:, :Bc], ii[:Bc])
+            else:
+                sub = synth.KnownLog(cfg_c, log.world, log.twist[:, :Bc], log.lm_idx[:, :Bc], log.z_xy[:, :Bc],
+                                     log.init_xy[:Bc])
             gpu_state = np.stack([bt.state(b) for b in range(Bc)])  # (state after the last leg that ran)
             out["cpu_baseline"] = cpu_baseline(sub, K, 1 + W, cores, gpu_state)
         print(json.dumps(out), flush=True)

@@ -35,6 +35,7 @@ SYMBOLS = [
     "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_get_state", "ekf_batch_get_cov",
     "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
     "ekf_set_update_mode", "ekf_batch_set_update_mode",
+    "ekf_default_sim_params", "ekf_batch_simulate_known_log", "ekf_batch_download_log", "ekf_batch_mc_stats",
     "ekf_circle_fit_scans",
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
 ]
@@ -54,6 +55,14 @@ class Params(C.Structure):
 
 class KnownLogC(C.Structure):
     _fields_ = [("T", C.c_int), ("vmax", C.c_int), ("twist", _dp), ("lm_idx", _ip), ("z_xy", _dp), ("init_xy", _dp)]
+
+
+class SimParams(C.Structure):
+    """ekf_sim_params (include/ekfslam.h): noise model of the reference's simulator."""
+    _fields_ = [("seed", C.c_ulonglong), ("first_filter_id", C.c_longlong), ("v_cmd", C.c_double), ("w_cmd", C.c_double),
+                ("vx_std", C.c_double), ("the_std", C.c_double), ("slip_min", C.c_double), ("slip_max", C.c_double),
+                ("sensor_std", C.c_double), ("max_visible_dis", C.c_double), ("wheel_base", C.c_double),
+                ("wheel_radius", C.c_double), ("ticks_per_step", C.c_int)]
 
 
 class RunStats(C.Structure):
@@ -84,6 +93,7 @@ def load():
     lib.ekf_last_error.restype = C.c_char_p
     lib.ekf_default_params.argtypes = [C.POINTER(Params)]
     lib.ekf_device_count.restype = C.c_int
+    lib.ekf_default_sim_params.argtypes = [C.POINTER(SimParams)]
     sig = {
         "ekf_create": [C.c_int, C.POINTER(Params), C.c_int, C.POINTER(h)],
         "ekf_destroy": [h],
@@ -116,6 +126,9 @@ def load():
         "ekf_batch_set_tuning": [h, C.c_int, C.c_int, C.c_int],
         "ekf_set_update_mode": [h, C.c_int],
         "ekf_batch_set_update_mode": [h, C.c_int],
+        "ekf_batch_simulate_known_log": [h, C.POINTER(SimParams), _dp, C.c_int, C.c_int],
+        "ekf_batch_download_log": [h, _dp, _ip, _dp, _dp, _dp],
+        "ekf_batch_mc_stats": [h, C.c_int, _dp],
         "ekf_circle_fit_scans": [C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _ip, _dp, _ip],
         "ekf_dense_create": [C.c_int, C.c_int, C.POINTER(h)],
         "ekf_dense_destroy": [h],
@@ -311,7 +324,37 @@ class BatchEKF:
             raise ValueError("log arrays must be twist[T,B,2], lm_idx[T,B,vmax], z_xy[T,B,vmax,2], init_xy[B,2n]")
         log = KnownLogC(T, li.shape[2], _d(tw), li.ctypes.data_as(_ip), _d(zz), _d(ii))
         _check(self._lib.ekf_batch_upload_known_log(self._h, C.byref(log)))
-        self.T = T
+        self.T, self._vmax = T, li.shape[2]
+
+    def simulate_known_log(self, cfg, world, steps=None, vmax=None):
+        """Generate the log ON THE DEVICE from a synth.SimConfig (same noise model and random-number
+        addressing as synth.make_known_log, which stays the host-side twin for the tests)."""
+        sp = SimParams()
+        self._lib.ekf_default_sim_params(C.byref(sp))
+        sp.seed, sp.first_filter_id = int(cfg.seed), int(cfg.first_filter_id)
+        sp.v_cmd, sp.w_cmd, sp.vx_std, sp.the_std = cfg.v_cmd, cfg.w_cmd, cfg.vx_std, cfg.the_std
+        sp.slip_min, sp.slip_max, sp.sensor_std, sp.max_visible_dis = cfg.slip_min, cfg.slip_max, cfg.sensor_std, cfg.max_visible_dis
+        sp.ticks_per_step = cfg.ticks_per_step
+        w = np.ascontiguousarray(world, dtype=np.float64)
+        if w.shape != (self.n, 2):
+            raise ValueError("world must be [n, 2]")
+        T = int(cfg.steps if steps is None else steps)
+        V = int(cfg.vmax if vmax is None else vmax)
+        _check(self._lib.ekf_batch_simulate_known_log(self._h, C.byref(sp), _d(w), T, V))
+        self.T, self._vmax = T, V
+
+    def download_log(self, want_truth=True):
+        T, B, V, n = self.T, self.B, self._vmax, self.n
+        tw, li, zz, ii = np.empty((T, B, 2)), np.empty((T, B, V), dtype=np.int32), np.empty((T, B, V, 2)), np.empty((B, 2 * n))
+        tp = np.empty((T, B, 3)) if want_truth else None
+        _check(self._lib.ekf_batch_download_log(self._h, _d(tw), li.ctypes.data_as(_ip), _d(zz), _d(ii),
+                                                _d(tp) if want_truth else None))
+        return tw, li, zz, ii, tp
+
+    def mc_stats(self, t):
+        out = np.empty(6)
+        _check(self._lib.ekf_batch_mc_stats(self._h, int(t), _d(out)))
+        return dict(zip(("nees_mean", "nees_max", "rmse_xy", "rmse_theta", "mean_trace_pose_cov", "frac_nees_below_95pct"), out))
 
     def run_known(self, t_begin=0, t_end=None, time_kernels=False):
         st = RunStats()

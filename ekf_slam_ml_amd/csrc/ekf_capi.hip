@@ -4,7 +4,9 @@
 #include "../../include/ekfslam.h"
 #include "ekf_kernels.hpp"
 #include "ekf_dense.hpp"
+#include "ekf_sim.hpp"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -93,6 +95,7 @@ struct Pool {
     int* log_lm = nullptr;
     double* log_z = nullptr;
     double* log_init = nullptr;
+    double* log_truth = nullptr;  // [T][B][3], simulated logs only
     size_t log_bytes = 0;
     std::vector<int> slot_active;  // [T][vmax]
 
@@ -215,7 +218,7 @@ struct Pool {
         if (stream) (void)hipStreamSynchronize(stream);
         void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, scores, meas_dev,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
-                        Uf, Vf, state_alt};
+                        Uf, Vf, state_alt, log_truth};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();
@@ -574,6 +577,115 @@ ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int non
     return EKF_OK;
 }
 
+void ekf_default_sim_params(ekf_sim_params* out) {
+    if (!out) return;
+    out->seed = 5000000ull;
+    out->first_filter_id = 0;
+    out->v_cmd = 0.5; out->w_cmd = 0.06;
+    out->vx_std = 0.01; out->the_std = 0.01;      // noise_param.yaml:3,5
+    out->slip_min = 0.90; out->slip_max = 1.10;   // noise_param.yaml:6-7
+    out->sensor_std = 0.005;                      // noise_param.yaml:8-9
+    out->max_visible_dis = 0.7;                   // noise_param.yaml:10
+    out->wheel_base = 0.16; out->wheel_radius = 0.033;  // fake_turtle_param.yaml:6-7
+    out->ticks_per_step = 10;
+}
+
+static ekf_status free_log(Pool& P) {
+    HIPC(hipStreamSynchronize(P.stream));
+    for (void* p : {(void*)P.log_twist, (void*)P.log_lm, (void*)P.log_z, (void*)P.log_init, (void*)P.log_truth})
+        if (p) HIPC(hipFree(p));
+    P.log_twist = nullptr; P.log_lm = nullptr; P.log_z = nullptr; P.log_init = nullptr; P.log_truth = nullptr;
+    P.T = 0; P.vmax = 0; P.log_bytes = 0;
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_simulate_known_log(ekf_batch_handle hb, const ekf_sim_params* sp, const double* world_xy, int T,
+                                        int vmax) {
+    if (!hb || !sp || !world_xy || T <= 0 || vmax < 0 || vmax > 64 || sp->ticks_per_step < 1)
+        return fail(EKF_ERR_INVALID, "ekf_batch_simulate_known_log: bad argument (vmax <= 64)");
+    Pool& P = hb->pool;
+    EKFC(P.use());
+    EKFC(free_log(P));
+    const int B = P.pv.B, n = P.pv.n;
+    const size_t n_tw = (size_t)T * B * 2, n_lm = (size_t)T * B * vmax, n_z = n_lm * 2, n_in = (size_t)B * 2 * n,
+                 n_tr = (size_t)T * B * 3;
+    HIPC(hipMalloc((void**)&P.log_twist, sizeof(double) * n_tw));
+    HIPC(hipMalloc((void**)&P.log_lm, sizeof(int) * (n_lm ? n_lm : 1)));
+    HIPC(hipMalloc((void**)&P.log_z, sizeof(double) * (n_z ? n_z : 1)));
+    HIPC(hipMalloc((void**)&P.log_init, sizeof(double) * (n_in ? n_in : 1)));
+    HIPC(hipMalloc((void**)&P.log_truth, sizeof(double) * n_tr));
+    P.log_bytes = sizeof(double) * (n_tw + n_z + n_in + n_tr) + sizeof(int) * n_lm;
+    double* d_world = nullptr;
+    int* d_active = nullptr;
+    const size_t n_act = (size_t)T * (vmax > 0 ? vmax : 1);
+    HIPC(hipMalloc((void**)&d_world, sizeof(double) * 2 * (n > 0 ? n : 1)));
+    HIPC(hipMalloc((void**)&d_active, sizeof(int) * n_act));
+    ekf_status st = EKF_OK;
+    auto body = [&]() -> ekf_status {
+        if (n > 0) HIPC(hipMemcpyAsync(d_world, world_xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, P.stream));
+        HIPC(hipMemsetAsync(d_active, 0, sizeof(int) * n_act, P.stream));
+        ekf::SimParams p{sp->seed, sp->first_filter_id, sp->v_cmd, sp->w_cmd, sp->vx_std, sp->the_std, sp->slip_min,
+                         sp->slip_max, sp->sensor_std, sp->max_visible_dis, sp->wheel_base, sp->wheel_radius,
+                         sp->ticks_per_step};
+        ekf::launch_sim(p, B, n, T, vmax, d_world, P.log_twist, P.log_truth, P.log_lm, P.log_z, P.log_init, d_active,
+                        P.stream);
+        HIPC(hipGetLastError());
+        std::vector<int> active(n_act, 0);
+        HIPC(hipMemcpyAsync(active.data(), d_active, sizeof(int) * n_act, hipMemcpyDeviceToHost, P.stream));
+        HIPC(hipStreamSynchronize(P.stream));
+        P.slot_active.swap(active);
+        return EKF_OK;
+    };
+    st = body();
+    (void)hipFree(d_world);
+    (void)hipFree(d_active);
+    if (st != EKF_OK) return st;
+    P.T = T;
+    P.vmax = vmax;
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_download_log(ekf_batch_handle hb, double* twist, int* lm_idx, double* z_xy, double* init_xy,
+                                  double* true_pose) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    Pool& P = hb->pool;
+    if (P.T <= 0) return fail(EKF_ERR_STATE, "no log on the device");
+    if (true_pose && !P.log_truth) return fail(EKF_ERR_STATE, "the uploaded log carries no simulated truth");
+    EKFC(P.use());
+    HIPC(hipStreamSynchronize(P.stream));
+    const size_t B = P.pv.B, T = P.T, vmax = P.vmax, n = P.pv.n;
+    if (twist) HIPC(hipMemcpy(twist, P.log_twist, sizeof(double) * T * B * 2, hipMemcpyDeviceToHost));
+    if (lm_idx && vmax) HIPC(hipMemcpy(lm_idx, P.log_lm, sizeof(int) * T * B * vmax, hipMemcpyDeviceToHost));
+    if (z_xy && vmax) HIPC(hipMemcpy(z_xy, P.log_z, sizeof(double) * T * B * vmax * 2, hipMemcpyDeviceToHost));
+    if (init_xy && n) HIPC(hipMemcpy(init_xy, P.log_init, sizeof(double) * B * 2 * n, hipMemcpyDeviceToHost));
+    if (true_pose) HIPC(hipMemcpy(true_pose, P.log_truth, sizeof(double) * T * B * 3, hipMemcpyDeviceToHost));
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_mc_stats(ekf_batch_handle hb, int t, double out[6]) {
+    if (!hb || !out) return fail(EKF_ERR_INVALID, "null argument");
+    Pool& P = hb->pool;
+    if (!P.log_truth) return fail(EKF_ERR_STATE, "ekf_batch_mc_stats needs a simulated log (ground truth)");
+    if (t < 0 || t >= P.T) return fail(EKF_ERR_INVALID, "step outside the log");
+    EKFC(P.use());
+    EKFC(P.flush());
+    ekf::launch_mc_stats(P.pv, P.log_truth + (size_t)t * P.pv.B * 3, P.digest_dev, P.stream);
+    EKFC(checked_launch());
+    std::vector<double> h((size_t)4 * P.pv.B);
+    EKFC(P.download(h.data(), P.digest_dev, sizeof(double) * h.size()));
+    double nees = 0, nmax = 0, p2 = 0, a2 = 0, tr = 0, inside = 0;
+    for (int b = 0; b < P.pv.B; b++) {
+        const double v = h[(size_t)b * 4];
+        nees += v; if (v > nmax) nmax = v;
+        p2 += h[(size_t)b * 4 + 1]; a2 += h[(size_t)b * 4 + 2]; tr += h[(size_t)b * 4 + 3];
+        if (v < 7.815) inside += 1.0;
+    }
+    const double Bn = (double)P.pv.B;
+    out[0] = nees / Bn; out[1] = nmax; out[2] = std::sqrt(p2 / Bn); out[3] = std::sqrt(a2 / Bn); out[4] = tr / Bn;
+    out[5] = inside / Bn;
+    return EKF_OK;
+}
+
 ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
     return hb->pool.set_update_mode(max_pending_corrections);
@@ -605,10 +717,7 @@ ekf_status ekf_batch_upload_known_log(ekf_batch_handle hb, const ekf_known_log* 
                 active[(size_t)t * vmax + v]++;
             }
         }
-    HIPC(hipStreamSynchronize(P.stream));
-    for (void* p : {(void*)P.log_twist, (void*)P.log_lm, (void*)P.log_z, (void*)P.log_init})
-        if (p) HIPC(hipFree(p));
-    P.log_twist = nullptr; P.log_lm = nullptr; P.log_z = nullptr; P.log_init = nullptr;
+    EKFC(free_log(P));
     const size_t n_tw = (size_t)T * B * 2, n_lm = (size_t)T * B * vmax, n_z = n_lm * 2, n_in = (size_t)B * 2 * n;
     HIPC(hipMalloc((void**)&P.log_twist, sizeof(double) * (n_tw ? n_tw : 1)));
     HIPC(hipMalloc((void**)&P.log_lm, sizeof(int) * (n_lm ? n_lm : 1)));

@@ -1,0 +1,212 @@
+// ekf_sim.hip -- on-device Monte-Carlo input generator and consistency statistics
+// (SURVEY.md section 8(f) row f4).  Reproduces, per filter, the value distributions of the reference's
+// simulator nurtlesim/src/tube_world.cpp (noisy commanded twist :191-208, wheel slip :214-227, robot-frame
+// landmark readings + Gaussian noise with a visibility radius :369-414) and the caller's odometry
+// marshalling (Odometer::getCurrentTwist, nuslam/src/slam.cpp:173-176), writing the compact
+// known-association log directly into HBM -- no 100-GB host logs for configs[4].
+//
+// Every random number is a pure function of (seed, global filter id, step, kind, k) through
+// splitmix64 + Box-Muller, the same addressing as the host generator ekf_slam_ml_amd/synth.py: integer
+// parts are bit-identical, transcendental parts (log/cos/sqrt) agree to rounding.
+#include "ekf_kernels.hpp"
+#include "ekf_sim.hpp"
+
+namespace ekf {
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    unsigned long long z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned long long sim_key(unsigned long long seed, unsigned long long fid,
+                                                      unsigned long long step, unsigned long long kind,
+                                                      unsigned long long k) {
+    const unsigned long long a = splitmix64(seed ^ (fid * 0xD1B54A32D192ED03ull));
+    const unsigned long long b = splitmix64(a + step * 0x8CB92BA72F3D8DD7ull);
+    const unsigned long long c = splitmix64(b + kind * 0xABC98388FB8FAC03ull);
+    return splitmix64(c + k);
+}
+__device__ __forceinline__ double uniform01(unsigned long long seed, unsigned long long fid, unsigned long long step,
+                                            unsigned long long kind, unsigned long long k) {
+    return (double)(sim_key(seed, fid, step, kind, k) >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double normal01(unsigned long long seed, unsigned long long fid, unsigned long long step,
+                                           unsigned long long kind, unsigned long long k) {
+    double u1 = uniform01(seed, fid, step, kind, 2 * k);
+    const double u2 = uniform01(seed, fid, step, kind, 2 * k + 1);
+    u1 = fmax(u1, 1.1102230246251565e-16);  // 2^-53
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * 3.141592653589793 * u2);
+}
+constexpr unsigned long long KIND_CMD = 1, KIND_SLIP = 2, KIND_SENSOR = 3;
+
+// DiffDrive::getBodyTwistForUpdate, rigid2d/src/diff_drive.cpp:38-47
+__device__ __forceinline__ void body_twist(const SimParams& p, double left, double right, double& ang, double& lin) {
+    const double D = p.wheel_base * 0.5, r = p.wheel_radius;
+    ang = (r / (2.0 * D)) * (right - left);
+    lin = (r / 2.0) * (right + left);
+}
+
+// One thread per filter: the true trajectory and the odometry twists of all T steps.
+__global__ void k_sim_trajectory(SimParams p, int B, int T, double* __restrict__ twist, double* __restrict__ truth) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long fid = (unsigned long long)p.first_filter_id + b;
+    double theta = 0.0, x = 0.0, y = 0.0;
+    for (int t = 0; t < T; t++) {
+        // callback_vel: noise only on non-zero commands (tube_world.cpp:191-208)
+        const double xv = p.v_cmd + (fabs(p.v_cmd) >= 1e-4 ? p.vx_std * normal01(p.seed, fid, t, KIND_CMD, 0) : 0.0);
+        const double av = p.w_cmd + (fabs(p.w_cmd) >= 1e-4 ? p.the_std * normal01(p.seed, fid, t, KIND_CMD, 1) : 0.0);
+        // DiffDrive::calculateWheelVelocity, diff_drive.cpp:24-36
+        const double D = p.wheel_base * 0.5, r = p.wheel_radius;
+        const double wl = -(D / r) * av + (1.0 / r) * xv, wr = (D / r) * av + (1.0 / r) * xv;
+        double dl = 0.0, dr = 0.0;
+        for (int k = 0; k < p.ticks_per_step; k++) {  // publishJointState, tube_world.cpp:214-227
+            const double sl = p.slip_min + (p.slip_max - p.slip_min) * uniform01(p.seed, fid, t, KIND_SLIP, 2 * k);
+            const double sr = p.slip_min + (p.slip_max - p.slip_min) * uniform01(p.seed, fid, t, KIND_SLIP, 2 * k + 1);
+            dl = (wl / 100.0) * sl;
+            dr = (wr / 100.0) * sr;
+            double dth, ddx;
+            body_twist(p, dl, dr, dth, ddx);
+            if (fabs(dth) < 1e-9) {
+                x = x + ddx * cos(theta);
+                y = y + ddx * sin(theta);
+            } else {
+                const double rad = ddx / dth;
+                const double nx = x - rad * sin(theta) + rad * sin(theta + dth);
+                const double ny = y + rad * cos(theta) - rad * cos(theta + dth);
+                x = nx; y = ny;
+            }
+            theta = theta + dth;
+        }
+        double ta, tx;
+        body_twist(p, dl * 10.0, dr * 10.0, ta, tx);  // Odometer::getCurrentTwist, slam.cpp:173-176
+        twist[((size_t)t * B + b) * 2] = ta;
+        twist[((size_t)t * B + b) * 2 + 1] = tx;
+        truth[((size_t)t * B + b) * 3] = theta;
+        truth[((size_t)t * B + b) * 3 + 1] = x;
+        truth[((size_t)t * B + b) * 3 + 2] = y;
+    }
+}
+
+// One workgroup per (filter, step): readings of the vmax nearest landmarks within the visibility radius,
+// in ascending landmark order (publishFakeSensor, tube_world.cpp:369-414).  Step 0 instead fills init_xy
+// with ALL n readings and leaves the slots empty (state_update_flag is still false, slam.cpp:315-327).
+__global__ __launch_bounds__(256) void k_sim_readings(SimParams p, int B, int n, int vmax,
+                                                      const double* __restrict__ world,
+                                                      const double* __restrict__ truth, int* __restrict__ lm_idx,
+                                                      double* __restrict__ z_xy, double* __restrict__ init_xy,
+                                                      int* __restrict__ slot_active) {
+    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const unsigned long long fid = (unsigned long long)p.first_filter_id + b;
+    const double th = truth[((size_t)t * B + b) * 3], px = truth[((size_t)t * B + b) * 3 + 1],
+                 py = truth[((size_t)t * B + b) * 3 + 2];
+    const double c = cos(th), s = sin(th);
+    int* slots = lm_idx + ((size_t)t * B + b) * vmax;
+    double* zz = z_xy + ((size_t)t * B + b) * vmax * 2;
+    if (t == 0) {
+        for (int i = tid; i < n; i += 256) {
+            const double dx = world[2 * i] - px, dy = world[2 * i + 1] - py;
+            init_xy[(size_t)b * 2 * n + 2 * i] = (c * dx + s * dy) + p.sensor_std * normal01(p.seed, fid, 0, KIND_SENSOR, 2ull * i);
+            init_xy[(size_t)b * 2 * n + 2 * i + 1] = (-s * dx + c * dy) + p.sensor_std * normal01(p.seed, fid, 0, KIND_SENSOR, 2ull * i + 1);
+        }
+        for (int v = tid; v < vmax; v += 256) { slots[v] = -1; zz[2 * v] = 0.0; zz[2 * v + 1] = 0.0; }
+        return;
+    }
+    __shared__ double sh_d[4];
+    __shared__ int sh_i[4];
+    __shared__ int chosen[64];
+    __shared__ int n_chosen;
+    __shared__ int exhausted;
+    const int kmax = vmax < 64 ? vmax : 64;
+    if (tid == 0) { n_chosen = 0; exhausted = 0; }
+    __syncthreads();
+    const double lim2 = p.max_visible_dis * p.max_visible_dis;
+    for (int pass = 0; pass < kmax; pass++) {
+        // nearest not-yet-chosen landmark (lexicographic (d2, i) minimum)
+        double best = 1.0e300;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 256) {
+            bool taken = false;
+            for (int q = 0; q < n_chosen; q++) taken |= (chosen[q] == i);
+            if (taken) continue;
+            const double dx = world[2 * i] - px, dy = world[2 * i + 1] - py;
+            const double rx = c * dx + s * dy, ry = -s * dx + c * dy;
+            const double d2 = rx * rx + ry * ry;
+            if (d2 < best || (d2 == best && i < bi)) { best = d2; bi = i; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_down(best, off, kWave);
+            const int oi = __shfl_down(bi, off, kWave);
+            if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+        }
+        if ((tid & 63) == 0) { sh_d[tid >> 6] = best; sh_i[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; w++)
+                if (sh_d[w] < best || (sh_d[w] == best && sh_i[w] < bi)) { best = sh_d[w]; bi = sh_i[w]; }
+            if (bi != 0x7fffffff && best <= lim2) chosen[n_chosen++] = bi;
+            else exhausted = 1;  // nothing left within the radius
+        }
+        __syncthreads();
+        if (exhausted) break;  // uniform
+    }
+    if (tid == 0) {
+        const int m = n_chosen;
+        for (int a = 1; a < m; a++) {  // ascending landmark index = loop order of ekf_slam.cpp:132
+            const int v = chosen[a];
+            int q = a - 1;
+            while (q >= 0 && chosen[q] > v) { chosen[q + 1] = chosen[q]; q--; }
+            chosen[q + 1] = v;
+        }
+        for (int v = 0; v < vmax; v++) {
+            if (v < m) {
+                const int i = chosen[v];
+                const double dx = world[2 * i] - px, dy = world[2 * i + 1] - py;
+                slots[v] = i;
+                zz[2 * v] = (c * dx + s * dy) + p.sensor_std * normal01(p.seed, fid, t, KIND_SENSOR, 2ull * i);
+                zz[2 * v + 1] = (-s * dx + c * dy) + p.sensor_std * normal01(p.seed, fid, t, KIND_SENSOR, 2ull * i + 1);
+                atomicAdd(&slot_active[(size_t)t * vmax + v], 1);
+            } else {
+                slots[v] = -1; zz[2 * v] = 0.0; zz[2 * v + 1] = 0.0;
+            }
+        }
+    }
+}
+
+// Monte-Carlo consistency of the batch against the simulated truth of step t: per filter the pose error
+// e = (wrap(theta - theta*), x - x*, y - y*), NEES = e^T P^-1 e with P = Sigma[0:3,0:3].
+// out[b][4] = {NEES, ex^2 + ey^2, etheta^2, trace P}
+__global__ void k_mc_stats(PoolView pv, const double* __restrict__ truth_t, double* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= pv.B) return;
+    const double* st = pv.state + (size_t)b * pv.ld;
+    const double* S = pv.sigma + (size_t)b * pv.sigma_stride;
+    const double e0 = normalize_angle(st[0] - truth_t[(size_t)b * 3]);
+    const double e1 = st[1] - truth_t[(size_t)b * 3 + 1], e2 = st[2] - truth_t[(size_t)b * 3 + 2];
+    const double a = S[0], bq = S[1], c = S[2], d = S[pv.ld], e = S[pv.ld + 1], f = S[pv.ld + 2], g = S[2 * pv.ld],
+                 h = S[2 * pv.ld + 1], i = S[2 * pv.ld + 2];
+    const double A = e * i - f * h, Bc = -(d * i - f * g), Cc = d * h - e * g;
+    const double det = a * A + bq * Bc + c * Cc;
+    // x = P^-1 e by the adjugate
+    const double x0 = (A * e0 + (c * h - bq * i) * e1 + (bq * f - c * e) * e2) / det;
+    const double x1 = (Bc * e0 + (a * i - c * g) * e1 + (c * d - a * f) * e2) / det;
+    const double x2 = (Cc * e0 + (bq * g - a * h) * e1 + (a * e - bq * d) * e2) / det;
+    out[(size_t)b * 4] = e0 * x0 + e1 * x1 + e2 * x2;
+    out[(size_t)b * 4 + 1] = e1 * e1 + e2 * e2;
+    out[(size_t)b * 4 + 2] = e0 * e0;
+    out[(size_t)b * 4 + 3] = a + e + i;
+}
+
+void launch_sim(const SimParams& p, int B, int n, int T, int vmax, const double* world, double* twist, double* truth,
+                int* lm_idx, double* z_xy, double* init_xy, int* slot_active, hipStream_t s) {
+    hipLaunchKernelGGL(k_sim_trajectory, dim3((B + 127) / 128), dim3(128), 0, s, p, B, T, twist, truth);
+    hipLaunchKernelGGL(k_sim_readings, dim3(B, T), dim3(256), 0, s, p, B, n, vmax, world, truth, lm_idx, z_xy, init_xy,
+                       slot_active);
+}
+
+void launch_mc_stats(const PoolView& pv, const double* truth_t, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_mc_stats, dim3((pv.B + 127) / 128), dim3(128), 0, s, pv, truth_t, out);
+}
+
+}  // namespace ekf

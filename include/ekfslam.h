@@ -151,6 +151,36 @@ ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]);
 ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal, int group_rows);
 ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal, int group_rows);
 
+/* ---- on-device Monte-Carlo inputs and consistency statistics --------
+ * Generates the known-association log of every filter ON THE DEVICE from the noise model of the
+ * reference's simulator (nurtlesim/src/tube_world.cpp:191-227,369-414; constants
+ * nurtlesim/config/noise_param.yaml:2-11) and the caller's odometry marshalling
+ * (nuslam/src/slam.cpp:173-176), instead of uploading it.  Every random number is a pure function of
+ * (seed, first_filter_id + b, step, kind, k), so shards of one job are reproducible independently. */
+typedef struct {
+    unsigned long long seed;
+    long long first_filter_id;   /* global id of filter 0 of this batch (multi-GPU sharding)          */
+    double v_cmd, w_cmd;         /* commanded twist (m/s, rad/s)                                       */
+    double vx_std, the_std;      /* noise_param.yaml:3,5   noise on the commanded twist                */
+    double slip_min, slip_max;   /* noise_param.yaml:6-7   wheel slip ~ U(slip_min, slip_max)          */
+    double sensor_std;           /* noise_param.yaml:8-9   per-axis reading noise                      */
+    double max_visible_dis;      /* noise_param.yaml:10    visibility radius                           */
+    double wheel_base, wheel_radius; /* rigid2d/config/fake_turtle_param.yaml:6-7                     */
+    int ticks_per_step;          /* 100 Hz simulator ticks per 10 Hz filter step (10)                  */
+} ekf_sim_params;
+void ekf_default_sim_params(ekf_sim_params* out);
+/* world_xy: [n][2] landmark positions (host).  Replaces any uploaded log; T steps, vmax reading slots. */
+ekf_status ekf_batch_simulate_known_log(ekf_batch_handle hb, const ekf_sim_params* sp, const double* world_xy,
+                                        int T, int vmax);
+/* Copies the device-resident log back (any pointer may be NULL): shapes as in ekf_known_log, plus
+ * true_pose [T][B][3] = simulated ground truth (theta, x, y) AFTER step t (simulated logs only). */
+ekf_status ekf_batch_download_log(ekf_batch_handle hb, double* twist, int* lm_idx, double* z_xy, double* init_xy,
+                                  double* true_pose);
+/* Consistency of the batch against the simulated truth of step t:
+ * out = {mean NEES (3 dof), max NEES, RMSE position, RMSE heading, mean trace of the pose covariance,
+ *        fraction of filters with NEES < 7.815 (95 % chi-square bound, 3 dof)}. */
+ekf_status ekf_batch_mc_stats(ekf_batch_handle hb, int t, double out[6]);
+
 /* Covariance update mode.  0 (default) = EAGER: every landmark correction streams Sigma once
  * (16 N^2 bytes) -- the contract path the roofline is quoted on.  k > 0 = DELAYED rank-2k update
  * (SURVEY.md section 8(f) f2): up to k corrections are kept as low-rank factors
