@@ -119,11 +119,12 @@ typedef struct {
 
 typedef struct {
     double elapsed_ms;        /* HIP-event time of the whole run on the batch's stream         */
-    double rank2_ms;          /* sum of the covariance rank-2 kernel's launch durations        */
-    long long rank2_launches; /* launches of that kernel in the run                            */
+    double rank2_ms;          /* sum of the durations of the covariance passes (time_kernels): */
+                              /* eager: the rank-2 kernel; delayed mode: the flush kernel      */
+    long long rank2_launches; /* covariance passes in the run (eager: one per correction slot) */
     long long corrections;    /* landmark corrections applied over all filters                 */
     long long filter_steps;   /* (prediction + measurement) pairs over all filters             */
-    double rank2_bytes_per_launch; /* algorithmic bytes: B_active * 2 * 8 * N^2 (average)      */
+    double rank2_bytes_per_launch; /* algorithmic bytes of one pass: (filters touched) * 2*8*N^2 */
 } ekf_run_stats;
 
 ekf_status ekf_batch_create(int B, int n, const ekf_params* params, int device, ekf_batch_handle* out);

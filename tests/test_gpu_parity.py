@@ -406,3 +406,20 @@ def test_batch_rejects_malformed_logs(hip):
     with pytest.raises(ValueError):
         bt.upload_known_log(log.twist[:, :1], log.lm_idx, log.z_xy, log.init_xy)
     bt.close()
+
+
+def test_config1_full_length_no_drift(hip, oracle):
+    """configs[0] at its full length (1000 steps, ~5300 corrections): rounding differences between the
+    structured HIP path and the dense-literal checker must not accumulate beyond the tolerance."""
+    steps = 1000
+    log = synth.make_known_log(synth.config1(steps=steps))
+    f, o = hip.EKF_SLAM(20), oracle.OracleEKF(20, oracle.DENSE)
+    for t in range(steps):
+        sensor, vis = log.expand_step(t)
+        f.prediction(log.twist[t, 0]); o.prediction(*log.twist[t, 0])
+        f.measurement(sensor, vis);    o.measurement(sensor, vis)
+    assert log.corrections > 5000
+    assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "1000 steps")
+    c = f.cov
+    assert np.abs(c - c.T).max() / np.abs(c).max() < 1e-12 and (np.linalg.eigvalsh(0.5 * (c + c.T)) > -1e-12).all()
+    f.close()
