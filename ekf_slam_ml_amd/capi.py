@@ -124,8 +124,8 @@ def load():
         "ekf_batch_get_poses": [h, _dp],
         "ekf_batch_checksum": [h, _dp],
         "ekf_batch_set_tuning": [h, C.c_int, C.c_int, C.c_int],
-        "ekf_set_update_mode": [h, C.c_int],
-        "ekf_batch_set_update_mode": [h, C.c_int],
+        "ekf_set_update_mode": [h, C.c_int, C.c_int],
+        "ekf_batch_set_update_mode": [h, C.c_int, C.c_int],
         "ekf_batch_simulate_known_log": [h, C.POINTER(SimParams), _dp, C.c_int, C.c_int],
         "ekf_batch_download_log": [h, _dp, _ip, _dp, _dp, _dp],
         "ekf_batch_mc_stats": [h, C.c_int, _dp],
@@ -281,9 +281,9 @@ class EKF_SLAM:
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
 
-    def set_update_mode(self, max_pending_corrections=0):
+    def set_update_mode(self, max_pending_corrections=0, symmetric_gather=False):
         """0 = eager covariance stream per correction; k > 0 = delayed rank-2k update (flush every k)."""
-        _check(self._lib.ekf_set_update_mode(self._h, int(max_pending_corrections)))
+        _check(self._lib.ekf_set_update_mode(self._h, int(max_pending_corrections), int(symmetric_gather)))
 
 
 class BatchEKF:
@@ -385,9 +385,9 @@ class BatchEKF:
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_batch_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
 
-    def set_update_mode(self, max_pending_corrections=0):
+    def set_update_mode(self, max_pending_corrections=0, symmetric_gather=False):
         """0 = eager covariance stream per correction; k > 0 = delayed rank-2k update (flush every k)."""
-        _check(self._lib.ekf_batch_set_update_mode(self._h, int(max_pending_corrections)))
+        _check(self._lib.ekf_batch_set_update_mode(self._h, int(max_pending_corrections), int(symmetric_gather)))
 
 
 class DensePropagator:

@@ -107,12 +107,14 @@ struct Pool {
     double* Vf = nullptr;
     double* state_alt = nullptr;
     int pend_cap = 0, pend_count = 0;
+    int pend_symmetric = 0;
 
-    ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count}; }
+    ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count, pend_symmetric}; }
 
-    ekf_status set_update_mode(int max_pending_corrections) {
+    ekf_status set_update_mode(int max_pending_corrections, int symmetric_gather) {
         EKFC(use());
         EKFC(flush());
+        pend_symmetric = symmetric_gather ? 1 : 0;
         HIPC(hipStreamSynchronize(stream));
         for (double** p : {&Uf, &Vf, &state_alt})
             if (*p) { HIPC(hipFree(*p)); *p = nullptr; }
@@ -388,7 +390,7 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
     Pool& c = (*out)->pool;
     EKFC(a.flush());
     EKFC(a.sync());
-    if (a.pend_cap > 0) EKFC(c.set_update_mode(a.pend_cap / 2));
+    if (a.pend_cap > 0) EKFC(c.set_update_mode(a.pend_cap / 2, a.pend_symmetric));
     HIPC(hipMemcpyAsync(c.pv.sigma, a.pv.sigma, sizeof(double) * a.pv.sigma_stride, hipMemcpyDeviceToDevice, c.stream));
     HIPC(hipMemcpyAsync(c.pv.state, a.pv.state, sizeof(double) * a.pv.ld, hipMemcpyDeviceToDevice, c.stream));
     c.init_flag = a.init_flag;
@@ -686,14 +688,14 @@ ekf_status ekf_batch_mc_stats(ekf_batch_handle hb, int t, double out[6]) {
     return EKF_OK;
 }
 
-ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections) {
+ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections, int symmetric_gather) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
-    return hb->pool.set_update_mode(max_pending_corrections);
+    return hb->pool.set_update_mode(max_pending_corrections, symmetric_gather);
 }
 
-ekf_status ekf_set_update_mode(ekf_handle h, int max_pending_corrections) {
+ekf_status ekf_set_update_mode(ekf_handle h, int max_pending_corrections, int symmetric_gather) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
-    return h->pool.set_update_mode(max_pending_corrections);
+    return h->pool.set_update_mode(max_pending_corrections, symmetric_gather);
 }
 
 ekf_status ekf_batch_upload_known_log(ekf_batch_handle hb, const ekf_known_log* log) {

@@ -125,9 +125,14 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int c = idx5(k, lm);
-            p[k].x = Sg[(size_t)r * ld + c];
-            p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
             g[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)c * ld + r);
+            if (pend.symmetric) {
+                p[k] = g[k];  // Sigma(r, c) taken as Sigma(c, r): coalesced instead of a 16-KB-strided gather
+                if (!two) p[k].y = 0.0;
+            } else {
+                p[k].x = Sg[(size_t)r * ld + c];
+                p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
+            }
         }
         for (int j = 0; j < rc; j += 2) {
             const double2_t ua = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
@@ -254,7 +259,7 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
     if (pend.count <= 0) return;
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
-    int rows = t.rows_per_block > 0 ? t.rows_per_block : 32;
+    int rows = t.rows_per_block > 0 ? t.rows_per_block : 16;  // measured: tools/flush_sweep.py
     const long long strips = (long long)pv.B * ((pv.ld / 2 + 255) / 256);
     if (t.rows_per_block <= 0 && strips * pv.N < 256LL * 8 * 32) rows = 8;
     dim3 grid((pv.ld / 2 + 255) / 256, (pv.N + rows - 1) / rows, pv.B);

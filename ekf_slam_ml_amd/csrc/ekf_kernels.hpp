@@ -37,6 +37,7 @@ struct Pending {
     double* V;
     int cap;
     int count;
+    int symmetric;  // 1: the gain step reads Sigma_base(c5, r) for Sigma_base(r, c5) (see ekf_set_update_mode)
 };
 
 struct Params {

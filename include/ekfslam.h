@@ -188,9 +188,13 @@ ekf_status ekf_batch_mc_stats(ekf_batch_handle hb, int t, double out[6]);
  * (Sigma = Sigma_base - sum K_j (H Sigma)_j), the rows/columns a correction needs are rebuilt on the
  * fly, prediction() maps the factors, and Sigma is rewritten once per k corrections (and before any
  * call that reads it: get_cov, checksum, clone, data_association, maha_scores).  Same results to
- * rounding (tested at 1e-9); k is capped at 64. */
-ekf_status ekf_set_update_mode(ekf_handle h, int max_pending_corrections);
-ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections);
+ * rounding (tested at 1e-9); k is capped at 64.
+ * symmetric_gather != 0 (delayed mode only): the gain step reads Sigma(c, r) where the reference reads
+ * Sigma(r, c) for the five columns of Sigma*H^T -- a coalesced row read instead of a 16-KB-strided
+ * column gather.  The reference never symmetrises Sigma, but (I - KH)Sigma keeps it symmetric to
+ * rounding (measured asymmetry 1e-18 relative), so results still agree at 1e-9. */
+ekf_status ekf_set_update_mode(ekf_handle h, int max_pending_corrections, int symmetric_gather);
+ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections, int symmetric_gather);
 
 /* ---- dense general-F covariance propagation, fp32 on the matrix cores (BASELINE.json configs[3]) ----
  * Sigma <- F * Sigma * F^T + Q for an ARBITRARY dense F: the reference's expression

@@ -93,3 +93,27 @@ def test_batch_delayed_n1000(hip, oracle):
             o.measurement_compact(log.init_xy[b], log.lm_idx[t, b], log.z_xy[t, b])
         assert_parity(bt.state(b), bt.cov(b), o.state, o.cov, FP64_TOL, f"filter {b}")
     bt.close()
+
+
+def test_symmetric_gather_option(hip, oracle):
+    """Delayed mode with Sigma(c, r) read for Sigma(r, c): still within the north_star tolerance."""
+    cfg = synth.SimConfig(n=60, steps=40, filters=4, seed=77, half_extent=2.0, min_spacing=0.2,
+                          max_visible_dis=0.9, vmax=4)
+    log = synth.make_known_log(cfg)
+    bt = hip.BatchEKF(4, 60)
+    bt.set_update_mode(16, symmetric_gather=True)
+    bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+    bt.run_known()
+    ref_s, ref_c, _ = oracle.batch_run_known(log, oracle.STRUCTURED, want_cov=True, fast=False)
+    for b in range(4):
+        assert_parity(bt.state(b), bt.cov(b), ref_s[b], ref_c[b], FP64_TOL, f"filter {b}")
+    bt.close()
+    f, o = hip.EKF_SLAM(200), oracle.OracleEKF(200, oracle.STRUCTURED)
+    f.set_update_mode(8, symmetric_gather=True)
+    log1 = synth.make_known_log(synth.config2(steps=40))
+    for t in range(40):
+        sensor, vis = log1.expand_step(t)
+        f.prediction(log1.twist[t, 0]); o.prediction(*log1.twist[t, 0])
+        f.measurement(sensor, vis);    o.measurement(sensor, vis)
+    assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "single filter, symmetric gather")
+    f.close()
