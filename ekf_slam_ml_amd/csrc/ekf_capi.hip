@@ -108,6 +108,8 @@ struct Pool {
     double* state_alt = nullptr;
     int pend_cap = 0, pend_count = 0;
     int pend_symmetric = 0;
+    int active_prefix = 1;  // data_association(): restrict corrections to the discovered prefix of the state
+    int touched_hwm = 0;    // landmarks [0, touched_hwm) may carry non-constructor covariance (single filter)
 
     ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count, pend_symmetric}; }
 
@@ -209,6 +211,7 @@ struct Pool {
     ekf_status reset() {
         EKFC(use());
         pend_count = 0;  // pending factors of the old run are dropped with it
+        touched_hwm = 0;
         ekf::launch_init(pv, stream);
         HIPC(hipGetLastError());
         init_flag = 0;
@@ -287,6 +290,7 @@ struct Pool {
         if (!in || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "set_cov: bad argument");
         EKFC(use());
         EKFC(flush());
+        touched_hwm = pv.n;  // caller-supplied covariance: no structure may be assumed any more
         const size_t w = sizeof(double) * pv.N;
         EKFC(stage_in.reserve(w * pv.N));
         EKFC(stage_in.wait());
@@ -395,6 +399,8 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
     HIPC(hipMemcpyAsync(c.pv.state, a.pv.state, sizeof(double) * a.pv.ld, hipMemcpyDeviceToDevice, c.stream));
     c.init_flag = a.init_flag;
     c.tuning = a.tuning;
+    c.touched_hwm = a.touched_hwm;
+    c.active_prefix = a.active_prefix;
     return c.sync();
 }
 
@@ -424,6 +430,7 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     bool first = !need_begin;
     for (int i = 0; i < n; i++) {  // ekf_slam.cpp:132-194, ascending landmark order
         if (!visible[i]) continue;
+        if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1;
         src.lm_imm = i;
         src.fresh_pose = first ? 1 : 0;
         src.write_snap = first ? 1 : 0;
@@ -451,18 +458,30 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     src.mode = ekf::SRC_ASSOC;
     src.assoc = P.pv.assoc;
     src.fresh_pose = 1;
+    // Landmarks are appended in discovery order (:318-327), so rows/columns beyond 3 + 2*(known_count + j + 1)
+    // -- and beyond every landmark this object has ever corrected (touched_hwm: known_list is caller-owned
+    // and may have holes) -- still hold their constructor values, and every correction of this call is
+    // exactly confined to that leading block: K and H*Sigma are exact zeros outside it.  (Non-finite
+    // states void this; they are already garbage in the reference.)
+    ekf::PoolView pva = P.pv;
     for (int j = 0; j < J; j++) {  // ekf_slam.cpp:291: sequential, state-carrying
         const double* mj = P.meas_dev + 2 * (size_t)j;
+        if (P.active_prefix) {
+            int m = known_count + j + 1 < n ? known_count + j + 1 : n;
+            if (P.touched_hwm > m) m = P.touched_hwm;
+            pva.N = 3 + 2 * m;
+        }
         ekf::launch_maha(P.pv, mj, P.scores, -1, P.stream);                               // :300-309
         ekf::launch_assoc_decide(P.pv, mj, P.scores, P.assoc_out_dev, 0, j, P.stream);    // :293-330
         src.meas = mj;
-        ekf::launch_gain(P.pv, src, P.stream);                                            // :331-385
-        ekf::launch_rank2(P.pv, P.tuning, P.stream);                                      // :389-390
+        ekf::launch_gain(pva, src, P.stream);                                             // :331-385
+        ekf::launch_rank2(pva, P.tuning, P.stream);                                       // :389-390
     }
     EKFC(checked_launch());
     ekf::AssocRec rec;
     EKFC(P.download(&rec, P.pv.assoc, sizeof(rec)));
     for (int i = known_count; i < rec.known_count && i < n; i++) known[i] = 1;  // :323
+    if (rec.known_count > P.touched_hwm) P.touched_hwm = rec.known_count < n ? rec.known_count : n;
     if (assoc_out) EKFC(P.download(assoc_out, P.assoc_out_dev, sizeof(int) * J));
     return EKF_OK;
 }
@@ -525,6 +544,11 @@ ekf_status ekf_get_init_flag(ekf_handle h, int* flag) {
 ekf_status ekf_set_init_flag(ekf_handle h, int flag) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     h->pool.init_flag = flag ? 1 : 0;
+    return EKF_OK;
+}
+ekf_status ekf_set_active_prefix(ekf_handle h, int enable) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    h->pool.active_prefix = enable ? 1 : 0;
     return EKF_OK;
 }
 ekf_status ekf_sync(ekf_handle h) {

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
 // wave-uniform and arrives through the scalar cache (lgkmcnt), off the vector-memory queue.
 // Sigma, K, G, rec and state never alias (__restrict__), so those scalar loads stay legal after the
 // first Sigma store.  The same workgroups apply state += K*nu (:186) and the theta wrap (:187).
-// grid (ceil(ld2n/256), row blocks, B).
+// grid (ceil(ceil(N/2)/256), row blocks, B).
 // ---------------------------------------------------------------------------------------------
 template <bool NT>
 __device__ __forceinline__ double2_t ld2(const double2_t* p) {
@@ -333,15 +333,19 @@ __global__ __launch_bounds__(256) void k_rank2(double* __restrict__ sigma, const
                                                const double* __restrict__ Gh_all, const CorrRec* __restrict__ rec,
                                                double* __restrict__ state, int N, int ld, size_t sigma_stride,
                                                int rows_per_block) {
+    // N is the ACTIVE dimension: rows and columns >= N are exactly untouched by this correction (their K
+    // and G entries are exact zeros), which data_association() exploits -- landmarks are appended in
+    // discovery order, so everything beyond 3 + 2*known_count still holds its constructor value.
     const int b = blockIdx.z;
     if (!rec[b].active) return;
     const int ld2n = ld >> 1;
+    const int ld2a = (N + 1) >> 1;  // double2 columns that hold an active column
     const int c2 = blockIdx.x * 256 + threadIdx.x;
     const double2_t* __restrict__ Kg = reinterpret_cast<const double2_t*>(Kg_all + (size_t)b * 2 * ld);
     const int row_begin = blockIdx.y * rows_per_block;
     const int row_end = min(N, row_begin + rows_per_block);
 
-    if (c2 < ld2n) {
+    if (c2 < ld2a) {
         const double2_t g0 = reinterpret_cast<const double2_t*>(Gh_all + (size_t)b * 2 * ld)[c2];
         const double2_t g1 = reinterpret_cast<const double2_t*>(Gh_all + (size_t)b * 2 * ld + ld)[c2];
         double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + c2;
@@ -596,8 +600,8 @@ void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s) {
 
 template <int U>
 static void launch_rank2_u(const PoolView& pv, int rows, bool nt, hipStream_t s) {
-    const int ld2n = pv.ld / 2;
-    dim3 grid((ld2n + 255) / 256, (pv.N + rows - 1) / rows, pv.B);
+    const int ld2a = (pv.N + 1) / 2;
+    dim3 grid((ld2a + 255) / 256, (pv.N + rows - 1) / rows, pv.B);
     if (nt)
         hipLaunchKernelGGL((k_rank2<U, true>), grid, dim3(256), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
                            pv.N, pv.ld, pv.sigma_stride, rows);

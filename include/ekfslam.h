@@ -100,6 +100,10 @@ ekf_status ekf_get_cov(ekf_handle h, double* out /* N*N row-major */);
 ekf_status ekf_set_cov(ekf_handle h, const double* in /* N*N row-major */);
 ekf_status ekf_get_init_flag(ekf_handle h, int* flag);  /* landmark_init_flag, ekf_slam.hpp:65 */
 ekf_status ekf_set_init_flag(ekf_handle h, int flag);
+/* data_association() appends landmarks in discovery order, so its corrections are exactly confined to the
+ * leading (3 + 2*known_count) block of the state; enable != 0 (default) streams only that block. Results are
+ * bit-identical to enable == 0 for finite states. */
+ekf_status ekf_set_active_prefix(ekf_handle h, int enable);
 /* Blocks until every kernel queued on the handle's stream has finished. */
 ekf_status ekf_sync(ekf_handle h);
 

@@ -423,3 +423,24 @@ def test_config1_full_length_no_drift(hip, oracle):
     c = f.cov
     assert np.abs(c - c.T).max() / np.abs(c).max() < 1e-12 and (np.linalg.eigvalsh(0.5 * (c + c.T)) > -1e-12).all()
     f.close()
+
+
+def test_active_prefix_is_bit_identical(hip):
+    """data_association() confined to the discovered prefix of the state must equal the full-width run
+    bit for bit (rows/columns of undiscovered landmarks receive exact zeros either way)."""
+    cfg = synth.config1(steps=80)
+    cfg.seed = 808
+    log = synth.make_unknown_log(cfg)
+    outs = []
+    for enable in (True, False):
+        f = hip.EKF_SLAM(20)
+        f.set_active_prefix(enable)
+        k = np.zeros(20, dtype=np.uint8)
+        dec = []
+        for t in range(80):
+            f.prediction(log.twist[t, 0])
+            dec.append(f.data_association(log.meas_xy[t, 0, :log.count[t, 0]], k).copy())
+        outs.append((f.state, f.cov, k.copy(), dec))
+        f.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2]) and all(np.array_equal(a, b) for a, b in zip(outs[0][3], outs[1][3]))
