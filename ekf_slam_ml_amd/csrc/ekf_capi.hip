@@ -71,6 +71,20 @@ struct Staging {
     }
 };
 
+// ring of pinned staging buffers: an upload only waits for the copy issued kRing uploads ago, so the
+// host keeps queueing work while the GPU is still busy with earlier calls
+struct StagingRing {
+    static constexpr int kRing = 8;
+    Staging slot[kRing];
+    int next = 0;
+    Staging& acquire() {
+        Staging& s = slot[next];
+        next = (next + 1) % kRing;
+        return s;
+    }
+    void release() { for (Staging& s : slot) s.release(); }
+};
+
 struct Pool {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -87,7 +101,8 @@ struct Pool {
     double* sensor_dev = nullptr;  // [2n] (single filter)
     double* digest_dev = nullptr;  // [B][4]
     double* poses_dev = nullptr;   // [B][3]
-    Staging stage_in, stage_out;
+    StagingRing stage_in;
+    Staging stage_out;
 
     // uploaded known-association log (device) + per-(step, slot) active-filter counts (host)
     int T = 0, vmax = 0;
@@ -110,6 +125,8 @@ struct Pool {
     int pend_symmetric = 0;
     int active_prefix = 1;  // data_association(): restrict corrections to the discovered prefix of the state
     int touched_hwm = 0;    // landmarks [0, touched_hwm) may carry non-constructor covariance (single filter)
+    int small_path = 1;     // measurement() of a small map runs as one LDS-resident launch (ekf_small.hip)
+    unsigned char* visible_dev = nullptr;  // [n] (single filter)
 
     ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count, pend_symmetric}; }
 
@@ -242,13 +259,18 @@ struct Pool {
     }
 
     // host -> device through the pinned staging buffer, ordered on the stream
-    ekf_status upload(void* dst, const void* src, size_t bytes) {
-        if (bytes == 0) return EKF_OK;
-        EKFC(stage_in.reserve(bytes));
-        EKFC(stage_in.wait());
-        std::memcpy(stage_in.host, src, bytes);
-        HIPC(hipMemcpyAsync(dst, stage_in.host, bytes, hipMemcpyHostToDevice, stream));
-        return stage_in.mark(stream);
+    ekf_status upload(void* dst, const void* src, size_t bytes) { return upload2(dst, src, bytes, nullptr, 0); }
+
+    // one H2D copy of two host pieces laid out back to back (piece 2 lands at dst + bytes1)
+    ekf_status upload2(void* dst, const void* src1, size_t bytes1, const void* src2, size_t bytes2) {
+        if (bytes1 + bytes2 == 0) return EKF_OK;
+        Staging& sg = stage_in.acquire();
+        EKFC(sg.reserve(bytes1 + bytes2));
+        EKFC(sg.wait());
+        std::memcpy(sg.host, src1, bytes1);
+        if (bytes2) std::memcpy(static_cast<char*>(sg.host) + bytes1, src2, bytes2);
+        HIPC(hipMemcpyAsync(dst, sg.host, bytes1 + bytes2, hipMemcpyHostToDevice, stream));
+        return sg.mark(stream);
     }
 
     // device -> host, blocking
@@ -292,12 +314,13 @@ struct Pool {
         EKFC(flush());
         touched_hwm = pv.n;  // caller-supplied covariance: no structure may be assumed any more
         const size_t w = sizeof(double) * pv.N;
-        EKFC(stage_in.reserve(w * pv.N));
-        EKFC(stage_in.wait());
-        std::memcpy(stage_in.host, in, w * pv.N);
-        HIPC(hipMemcpy2DAsync(pv.sigma + (size_t)b * pv.sigma_stride, sizeof(double) * pv.ld, stage_in.host, w, w,
+        Staging& sg = stage_in.acquire();
+        EKFC(sg.reserve(w * pv.N));
+        EKFC(sg.wait());
+        std::memcpy(sg.host, in, w * pv.N);
+        HIPC(hipMemcpy2DAsync(pv.sigma + (size_t)b * pv.sigma_stride, sizeof(double) * pv.ld, sg.host, w, w,
                               pv.N, hipMemcpyHostToDevice, stream));
-        return stage_in.mark(stream);
+        return sg.mark(stream);
     }
 
     ekf_status ensure_meas_capacity(int J) {
@@ -368,7 +391,10 @@ ekf_status ekf_create(int n, const ekf_params* params, int device, ekf_handle* o
     ekf_filter_s* f = new (std::nothrow) ekf_filter_s();
     if (!f) return fail(EKF_ERR_NOMEM, "host allocation failed");
     ekf_status st = f->pool.create(1, n, params, device);
-    if (st == EKF_OK) st = f->pool.dalloc(&f->pool.sensor_dev, (size_t)(n > 0 ? 2 * n : 2));
+    // sensor_reading (2n doubles) and visible_list (n bytes) share one buffer so one copy brings both
+    if (st == EKF_OK) st = f->pool.dalloc(&f->pool.sensor_dev, (size_t)(n > 0 ? 2 * n : 2) + (size_t)(n + 15) / 8);
+    if (st == EKF_OK) f->pool.visible_dev = reinterpret_cast<unsigned char*>(f->pool.sensor_dev + (n > 0 ? 2 * n : 2));
+    if (st == EKF_OK && ekf::small_prepare() != hipSuccess) st = fail(EKF_ERR_HIP, "hipFuncSetAttribute failed");
     if (st != EKF_OK) {
         f->pool.destroy();
         delete f;
@@ -400,6 +426,7 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
     c.init_flag = a.init_flag;
     c.tuning = a.tuning;
     c.touched_hwm = a.touched_hwm;
+    c.small_path = a.small_path;
     c.active_prefix = a.active_prefix;
     return c.sync();
 }
@@ -417,7 +444,15 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     Pool& P = h->pool;
     EKFC(P.use());
     const int n = P.pv.n;
-    EKFC(P.upload(P.sensor_dev, sensor_xy, sizeof(double) * 2 * n));
+    EKFC(P.upload2(P.sensor_dev, sensor_xy, sizeof(double) * 2 * n, visible, (size_t)n));
+    if (P.small_path && P.pend_cap == 0 && P.pv.N <= ekf::small_max_dim() && n > 0) {
+        // small map (the reference runs n = 20): the whole call in one LDS-resident launch
+        ekf::launch_small_measure(P.pv, P.sensor_dev, P.visible_dev, !P.init_flag, P.stream);
+        P.init_flag = 1;
+        for (int i = n - 1; i >= 0; i--)
+            if (visible[i]) { if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1; break; }
+        return checked_launch();
+    }
     // ekf_slam.cpp:109-128.  The pose capture needs its own launch only together with the first-call
     // landmark initialisation; afterwards the first correction of the call records the pose it reads
     // (no correction has moved it yet) and the later ones use that record.
@@ -544,6 +579,11 @@ ekf_status ekf_get_init_flag(ekf_handle h, int* flag) {
 ekf_status ekf_set_init_flag(ekf_handle h, int flag) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     h->pool.init_flag = flag ? 1 : 0;
+    return EKF_OK;
+}
+ekf_status ekf_set_small_map_path(ekf_handle h, int enable) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    h->pool.small_path = enable ? 1 : 0;
     return EKF_OK;
 }
 ekf_status ekf_set_active_prefix(ekf_handle h, int enable) {

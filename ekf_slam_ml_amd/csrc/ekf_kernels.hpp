@@ -186,6 +186,11 @@ void launch_circles(const double* ranges, int S, int nb, int max_out, double* ce
                     double* all_out, int* n_clusters, hipStream_t s);
 int circles_max_beams();
 int circles_max_clusters();
+// whole measurement() call of a SMALL map in one single-workgroup, LDS-resident launch (ekf_small.hip)
+void launch_small_measure(const PoolView& pv, const double* sensor, const unsigned char* visible, int do_init,
+                          hipStream_t s);
+int small_max_dim();          // largest N = 3 + 2n the small path accepts
+hipError_t small_prepare();   // raises the kernel's dynamic-LDS limit (87 KB > 64 KB default)
 int max_pending();  // capacity limit of the delayed-update factor store (rows of U / V per filter)
 void launch_gather_poses(const PoolView& pv, double* out, hipStream_t s);
 

@@ -1,0 +1,118 @@
+// ekf_small.hip -- single-workgroup, LDS-resident measurement() for small maps.
+//
+// At the reference's own operating point (n = 20 landmarks, N = 43, nuslam/src/slam.cpp:250) the whole
+// covariance is 15 KB: streaming it through HBM with two launches per visible landmark is all launch
+// latency.  Here ONE workgroup loads Sigma and the state into LDS, runs the entire measurement() call --
+// pose capture, first-call landmark initialisation, and every visible landmark's correction in ascending
+// order (ekf_slam.cpp:108-197) -- with workgroup barriers between the phases, and writes both back:
+// one launch per API call instead of 2V + 1.  The arithmetic (gather order, summation order, update
+// expression) is that of k_gain / k_rank2, so the result is bit-identical to the multi-kernel path.
+// LDS rows use an odd stride so that the column gather Sigma(r, c5) is bank-conflict-free.
+#include "ekf_kernels.hpp"
+
+namespace ekf {
+
+constexpr int kSmallThreads = 256;
+
+__global__ __launch_bounds__(kSmallThreads) void k_small_measure(PoolView pv, const double* __restrict__ sensor,
+                                                                 const unsigned char* __restrict__ visible,
+                                                                 int do_init) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = pv.N, ld = pv.ld, n = pv.n;
+    const int ldS = N | 1;
+    double* S = sm;            // [N][ldS]
+    double* st = S + (size_t)N * ldS;  // [N]
+    double* Gg = st + N;       // [2][N]
+    __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
+
+    double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    double* stg = pv.state + (size_t)b * ld;
+    const double* sens = sensor + (size_t)b * 2 * n;
+    const unsigned char* vis = visible + (size_t)b * n;
+    for (int r = tid >> 6; r < N; r += kSmallThreads / 64)
+        for (int c = tid & 63; c < N; c += 64) S[r * ldS + c] = Sg[(size_t)r * ld + c];
+    for (int r = tid; r < N; r += kSmallThreads) st[r] = stg[r];
+    __syncthreads();
+
+    const double theta = st[0], x = st[1], y = st[2];  // captured ONCE, ekf_slam.cpp:109-111
+    if (do_init) {                                     // :113-128, all n landmarks regardless of visibility
+        __syncthreads();                               // everybody holds the pose before the map is rewritten
+        for (int i = tid; i < n; i += kSmallThreads) {
+            const double sx = sens[2 * i], sy = sens[2 * i + 1];
+            const double ri = sqrt(sx * sx + sy * sy);
+            const double phii = atan2(sy, sx);
+            st[2 * i + 3] = x + ri * cos(phii + theta);
+            st[2 * i + 3 + 1] = y + ri * sin(phii + theta);
+        }
+        __syncthreads();
+    }
+
+    for (int lm = 0; lm < n; lm++) {  // :132-194 (uniform loop: every lane sees the same visible[] byte)
+        if (!vis[lm]) continue;
+        if (tid == 0) {
+            MeasTerms m;
+            measurement_terms(st[2 * lm + 3], st[2 * lm + 4], sens[2 * lm], sens[2 * lm + 1], theta, x, y, m);
+            double S55[5][5], Sm[2][2], Si[2][2];
+            for (int k = 0; k < 5; k++)
+                for (int l = 0; l < 5; l++) S55[k][l] = S[idx5(k, lm) * ldS + idx5(l, lm)];
+            innovation_cov(S55, m.H, pv.p.r_meas, Sm);
+            inv2(Sm, Si);
+            for (int a = 0; a < 2; a++)
+                for (int k = 0; k < 5; k++) sh_H[a * 5 + k] = m.H[a][k];
+            sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
+            sh_nu[0] = m.z0 - m.zh0;                   // :182
+            sh_nu[1] = normalize_angle(m.z1 - m.zh1);  // :183
+        }
+        __syncthreads();
+        double k0 = 0.0, k1 = 0.0;
+        const int r = tid;
+        if (r < N) {
+            double sht0 = 0.0, sht1 = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int c = idx5(k, lm);
+                const double p = S[r * ldS + c];
+                const double g = S[c * ldS + r];
+                sht0 += p * sh_H[k];
+                sht1 += p * sh_H[5 + k];
+                g0 += sh_H[k] * g;
+                g1 += sh_H[5 + k] * g;
+            }
+            k0 = sht0 * sh_Si[0] + sht1 * sh_Si[2];  // :178
+            k1 = sht0 * sh_Si[1] + sht1 * sh_Si[3];
+            Gg[r] = g0;
+            Gg[N + r] = g1;
+        }
+        __syncthreads();
+        // Sigma <- (I - K H) Sigma (:191-192): lane tid owns row tid's K, so rows are walked by their owner
+        if (r < N) {
+            double* row = S + r * ldS;
+            for (int c = 0; c < N; c++) row[c] = row[c] - (k0 * Gg[c] + k1 * Gg[N + c]);
+            double s = st[r] + (k0 * sh_nu[0] + k1 * sh_nu[1]);  // :186
+            if (r == 0) s = normalize_angle(s);                  // :187
+            st[r] = s;
+        }
+        __syncthreads();
+    }
+
+    for (int r = tid >> 6; r < N; r += kSmallThreads / 64)
+        for (int c = tid & 63; c < N; c += 64) Sg[(size_t)r * ld + c] = S[r * ldS + c];
+    for (int r = tid; r < N; r += kSmallThreads) stg[r] = st[r];
+}
+
+size_t small_lds_bytes(int N) { return sizeof(double) * ((size_t)N * (N | 1) + 3 * (size_t)N); }
+int small_max_dim() { return kSmallThreads < 104 ? kSmallThreads : 104; }  // N <= 104: 87 KB of LDS, one lane per row
+
+hipError_t small_prepare() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_measure),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
+}
+
+void launch_small_measure(const PoolView& pv, const double* sensor, const unsigned char* visible, int do_init,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_small_measure, dim3(pv.B), dim3(kSmallThreads), small_lds_bytes(pv.N), s, pv, sensor, visible,
+                       do_init);
+}
+
+}  // namespace ekf

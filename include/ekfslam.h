@@ -104,6 +104,10 @@ ekf_status ekf_set_init_flag(ekf_handle h, int flag);
  * leading (3 + 2*known_count) block of the state; enable != 0 (default) streams only that block. Results are
  * bit-identical to enable == 0 for finite states. */
 ekf_status ekf_set_active_prefix(ekf_handle h, int enable);
+/* Small maps (N = 3 + 2n <= 104, e.g. the reference's n = 20): measurement() runs as ONE single-workgroup,
+ * LDS-resident launch instead of 2 launches per visible landmark; enable != 0 is the default.  Bit-identical
+ * to the multi-kernel path. */
+ekf_status ekf_set_small_map_path(ekf_handle h, int enable);
 /* Blocks until every kernel queued on the handle's stream has finished. */
 ekf_status ekf_sync(ekf_handle h);
 

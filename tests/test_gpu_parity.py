@@ -444,3 +444,21 @@ def test_active_prefix_is_bit_identical(hip):
         f.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][2], outs[1][2]) and all(np.array_equal(a, b) for a, b in zip(outs[0][3], outs[1][3]))
+
+
+@pytest.mark.parametrize("n", [1, 20, 50, 51])
+def test_small_map_path_is_bit_identical(hip, n):
+    """measurement() as one LDS-resident launch (N <= 104) vs the gain + rank-2 kernel pair."""
+    cfg = synth.SimConfig(n=n, steps=40, seed=300 + n, half_extent=1.5, min_spacing=0.1, max_visible_dis=0.9, vmax=n)
+    log = synth.make_known_log(cfg)
+    outs = []
+    for enable in (True, False):
+        f = hip.EKF_SLAM(n)
+        f.set_small_map_path(enable)
+        for t in range(40):
+            sensor, vis = log.expand_step(t)
+            f.prediction(log.twist[t, 0]); f.measurement(sensor, vis)
+        outs.append((f.state, f.cov))
+        f.close()
+    assert log.corrections > 20
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
