@@ -13,7 +13,7 @@
 //
 // Kernel: 128 x 128 block tile, BK = 32, 4 waves each owning a 64 x 64 sub-tile = 2 x 2
 // v_mfma_f32_32x32x2_f32 accumulators (exact f32 FMA chains, 64 FLOP/clk/SIMD = the f32 peak).
-// Operands go global -> registers -> LDS (double-buffered, one barrier per K tile); LDS images are
+// Operands go global -> registers -> LDS (the next K tile's global loads fly under the MFMAs); LDS images are
 // [k][i] with an odd row stride so that both the transposing b32 stores and the fragment reads
 // (lanes 0-31 = 32 consecutive i at one k, lanes 32-63 the next k) are bank-conflict-free.
 // Matrices are ld x ld with ld a multiple of 128 and zero padding, so no tile is ragged.
@@ -49,8 +49,10 @@ __device__ __forceinline__ void tile_of(int bid, int tiles, int& tm, int& tn) {
     tn = in_g / gm;
 }
 
-template <bool BT>
-__global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B,
+// NBUF = 2: double-buffered LDS (66 KB, 2 workgroups per CU, one barrier per K tile);
+// NBUF = 1: single buffer (33 KB, 4 workgroups per CU, two barriers per K tile).
+template <bool BT, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 4) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B,
                                                      float* __restrict__ C, const float* __restrict__ Qadd, int ld,
                                                      int tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
     lstore(0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
+        const int cur = NBUF == 2 ? (kt & 1) : 0;
         if (kt + 1 < nk) gload((kt + 1) * BK);  // next tile's global loads fly under this tile's MFMAs
         const float* as = smem + cur * BUF_ELEMS + wm * 64 + li;
         const float* bs = smem + cur * BUF_ELEMS + A_ELEMS + wn * 64 + li;
@@ -151,8 +153,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
             a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
         }
         if (kt + 1 < nk) {
-            lstore(cur ^ 1);  // the other buffer was last read one barrier ago
-            __syncthreads();
+            if constexpr (NBUF == 2) {
+                lstore(cur ^ 1);  // the other buffer was last read one barrier ago
+                __syncthreads();
+            } else {
+                __syncthreads();  // every wave is done reading the only buffer
+                lstore(0);
+                __syncthreads();
+            }
         }
     }
 
@@ -173,27 +181,40 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
             }
 }
 
+// Measured at N = 10003 (tools/dense_bench.py): single buffer 123.6 TFLOP/s, double buffer 122.0 -- the
+// extra resident waves hide the second barrier, and 4 workgroups per CU need only 33 KB of LDS each.
+static int g_dense_nbuf = 1;
+void dense_gemm_set_buffers(int nbuf) { g_dense_nbuf = nbuf == 1 ? 1 : 2; }
+
 size_t dense_gemm_lds_bytes(bool bt) {
     const int a = BK * SA, b = bt ? BK * SBT : BK * SBN;
-    return (size_t)2 * (a + b) * sizeof(float);
+    return (size_t)g_dense_nbuf * (a + b) * sizeof(float);
 }
 
 hipError_t dense_gemm_prepare() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense_gemm_lds_bytes(true));
+    const int a = BK * SA;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32<true, 2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (a + BK * SBT) * sizeof(float)));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense_gemm_lds_bytes(false));
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32<false, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (a + BK * SBN) * sizeof(float)));
 }
 
 void launch_dense_gemm(const float* A, const float* B, float* C, const float* Qadd, int ld, bool b_transposed,
                        hipStream_t s) {
     const int tiles = ld / BM;
     dim3 grid(tiles * tiles);
-    if (b_transposed)
-        hipLaunchKernelGGL((k_gemm_f32<true>), grid, dim3(256), dense_gemm_lds_bytes(true), s, A, B, C, Qadd, ld, tiles);
-    else
-        hipLaunchKernelGGL((k_gemm_f32<false>), grid, dim3(256), dense_gemm_lds_bytes(false), s, A, B, C, Qadd, ld, tiles);
+    if (g_dense_nbuf == 2) {
+        if (b_transposed)
+            hipLaunchKernelGGL((k_gemm_f32<true, 2>), grid, dim3(256), dense_gemm_lds_bytes(true), s, A, B, C, Qadd, ld, tiles);
+        else
+            hipLaunchKernelGGL((k_gemm_f32<false, 2>), grid, dim3(256), dense_gemm_lds_bytes(false), s, A, B, C, Qadd, ld, tiles);
+    } else {
+        if (b_transposed)
+            hipLaunchKernelGGL((k_gemm_f32<true, 1>), grid, dim3(256), dense_gemm_lds_bytes(true), s, A, B, C, Qadd, ld, tiles);
+        else
+            hipLaunchKernelGGL((k_gemm_f32<false, 1>), grid, dim3(256), dense_gemm_lds_bytes(false), s, A, B, C, Qadd, ld, tiles);
+    }
 }
 
 }  // namespace ekf

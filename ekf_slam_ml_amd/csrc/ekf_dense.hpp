@@ -10,5 +10,6 @@ constexpr int kDenseTile = 128;  // ld must be a multiple of this
 void launch_dense_gemm(const float* A, const float* B, float* C, const float* Qadd, int ld, bool b_transposed,
                        hipStream_t s);
 size_t dense_gemm_lds_bytes(bool b_transposed);
+void dense_gemm_set_buffers(int nbuf);  // 1 (default) or 2 LDS buffers per workgroup
 hipError_t dense_gemm_prepare();  // raises the dynamic-LDS limit of both instantiations (66 KB > 64 KB default)
 }  // namespace ekf
