@@ -200,11 +200,15 @@ __device__ __forceinline__ void flush_store(const double2_t (&a)[U_ROWS], double
 template <int U_ROWS>
 __device__ __forceinline__ void flush_apply(double2_t (&a)[U_ROWS], const double* __restrict__ Ub,
                                             const double2_t* __restrict__ Vb, int r, int ld, int ld2n, int count) {
+    // V of pair j+2 AND j+4 are in flight while pair j's FMAs run (PMC: with one pair of lookahead the waves
+    // sat in s_waitcnt half of the time: an L2 hit under load outlasts one pair's 256 FMA cycles).  Trips past
+    // the end re-read pair 0.
+    const int j1 = 2 < count ? 2 : 0;
     double2_t v0 = Vb[0], v1 = Vb[ld2n];
+    double2_t v0n = Vb[(size_t)j1 * ld2n], v1n = Vb[(size_t)(j1 + 1) * ld2n];
     for (int j = 0; j < count; j += 2) {
-        // V of the NEXT pair is requested before this pair's FMAs (the last trip re-reads pair 0)
-        const int jn = j + 2 < count ? j + 2 : 0;
-        const double2_t v0n = Vb[(size_t)jn * ld2n], v1n = Vb[(size_t)(jn + 1) * ld2n];
+        const int jn = j + 4 < count ? j + 4 : 0;
+        const double2_t v0nn = Vb[(size_t)jn * ld2n], v1nn = Vb[(size_t)(jn + 1) * ld2n];
         const double* __restrict__ u0 = Ub + (size_t)j * ld + r;  // wave-uniform -> scalar loads
         const double* __restrict__ u1 = u0 + ld;
 #pragma unroll
@@ -213,8 +217,8 @@ __device__ __forceinline__ void flush_apply(double2_t (&a)[U_ROWS], const double
             a[u].x = __builtin_fma(k1, v1.x, __builtin_fma(k0, v0.x, a[u].x));
             a[u].y = __builtin_fma(k1, v1.y, __builtin_fma(k0, v0.y, a[u].y));
         }
-        v0 = v0n;
-        v1 = v1n;
+        v0 = v0n; v1 = v1n;
+        v0n = v0nn; v1n = v1nn;
     }
 }
 
@@ -224,11 +228,26 @@ __device__ __forceinline__ void flush_apply(double2_t (&a)[U_ROWS], const double
 template <int U_ROWS, bool NT>
 __global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const double* __restrict__ Uall,
                                                const double* __restrict__ Vall, int N, int ld, size_t sigma_stride,
-                                               int cap, int count, int rows_per_block) {
-    const int b = blockIdx.z;
+                                               int cap, int count, int rows_per_block, int strips,
+                                               int row_blocks, int B) {
+    // 1-D grid, XCD-aware decode (speed only): workgroup ids are dealt round-robin to the 8 XCDs, each with
+    // its own 4 MB L2.  All workgroups of one filter re-read that filter's factors (count x 32 KB), so a
+    // filter is given to ONE XCD: id -> (xcd = id % 8, slot = id / 8), filter = 8 * (slot / P) + xcd.
+    const int P = strips * row_blocks;
+    int b, p;
+    const int full = (B / 8) * 8 * P;
+    if ((int)blockIdx.x < full) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b = (slot / P) * 8 + xcd;
+        p = slot % P;
+    } else {  // the last B % 8 filters: plain order
+        const int rest = blockIdx.x - full;
+        b = (B / 8) * 8 + rest / P;
+        p = rest % P;
+    }
     const int ld2n = ld >> 1;
-    const int c2 = blockIdx.x * 256 + threadIdx.x;
-    const int row_begin = blockIdx.y * rows_per_block;
+    const int c2 = (p % strips) * 256 + threadIdx.x;
+    const int row_begin = (p / strips) * rows_per_block;
     const int row_end = min(N, row_begin + rows_per_block);
     if (c2 >= ld2n) return;
     const double* __restrict__ Ub = Uall + (size_t)b * cap * ld;
@@ -260,10 +279,12 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
     int rows = t.rows_per_block > 0 ? t.rows_per_block : 16;  // measured: tools/flush_sweep.py
-    const long long strips = (long long)pv.B * ((pv.ld / 2 + 255) / 256);
-    if (t.rows_per_block <= 0 && strips * pv.N < 256LL * 8 * 32) rows = 8;
-    dim3 grid((pv.ld / 2 + 255) / 256, (pv.N + rows - 1) / rows, pv.B);
-#define EKF_FL_ARGS pv.sigma, pend.U, pend.V, pv.N, pv.ld, pv.sigma_stride, pend.cap, pend.count, rows
+    const long long all_strips = (long long)pv.B * ((pv.ld / 2 + 255) / 256);
+    if (t.rows_per_block <= 0 && all_strips * pv.N < 256LL * 8 * 32) rows = 8;
+    const int strips = (pv.ld / 2 + 255) / 256, row_blocks = (pv.N + rows - 1) / rows;
+    dim3 grid((unsigned)((long long)strips * row_blocks * pv.B));
+#define EKF_FL_ARGS pv.sigma, pend.U, pend.V, pv.N, pv.ld, pv.sigma_stride, pend.cap, pend.count, rows, strips, \
+    row_blocks, pv.B
     if (rows >= 16) {
         if (nt) hipLaunchKernelGGL((k_flush<16, true>), grid, dim3(256), 0, s, EKF_FL_ARGS);
         else hipLaunchKernelGGL((k_flush<16, false>), grid, dim3(256), 0, s, EKF_FL_ARGS);
