@@ -117,3 +117,22 @@ def test_symmetric_gather_option(hip, oracle):
         f.measurement(sensor, vis);    o.measurement(sensor, vis)
     assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "single filter, symmetric gather")
     f.close()
+
+
+@pytest.mark.parametrize("B", [8, 11, 17])
+def test_flush_grid_decode_for_any_batch_size(hip, B):
+    """The flush kernel's XCD-aware 1-D grid (filters dealt to XCDs in groups of 8 + a plain remainder)
+    must cover every filter exactly once: delayed == eager for batch sizes around the group size."""
+    cfg = synth.SimConfig(n=150, steps=10, filters=B, seed=900 + B, half_extent=3.0, min_spacing=0.2,
+                          max_visible_dis=1e9, vmax=3)
+    log = synth.make_known_log(cfg)
+    res = []
+    for k in (0, 6):
+        bt = hip.BatchEKF(B, 150)
+        bt.set_update_mode(k)
+        bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+        bt.run_known()
+        res.append([(bt.state(b), bt.cov(b)) for b in range(B)])
+        bt.close()
+    for b in range(B):
+        assert_parity(res[1][b][0], res[1][b][1], res[0][b][0], res[0][b][1], 1e-11, f"B={B} filter {b}")
