@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--cpu-filters", type=int, default=0)
     ap.add_argument("--delayed-k", type=int, default=32,
                     help="also time the delayed rank-2k update with this many corrections per flush (0 = skip)")
+    ap.add_argument("--no-active-set", action="store_true", help="skip the active-set leg")
     ap.add_argument("--host-log", action="store_true",
                     help="generate the synthetic log on the host (numpy) and upload it, instead of on the device")
     ap.add_argument("--rows", type=int, default=0)
@@ -167,6 +168,35 @@ def main():
                                "k corrections; results equal the eager path to rounding (tests/test_gpu_delayed.py)"}
         bt.set_update_mode(0)
 
+    # Third, separately reported leg: the eager correction restricted to the rows of the TOUCHED set (exact,
+    # bit-identical; SURVEY.md section 7 "exact active-set sparsity").  Its cost depends on how many landmarks
+    # a filter has corrected so far (here <= 2 per step), not on n -- it says nothing about the dense roofline.
+    active = None
+    if not a.no_active_set:
+        bt.reset()
+        bt.set_active_set(True)
+        bt.run_known(0, 1 + W)
+        fence()
+        t0 = time.perf_counter()
+        sa = bt.run_known(1 + W, 1 + W + K, time_kernels=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fence()
+        awall, acorr, _ = shard.reduce_throughput(t1 - t0, float(sa["corrections"]), float(sa["filter_steps"]),
+                                                  device=red_dev)
+        if rank == 0:
+            astate = [bt.state(b) for b in range(min(B, 4))]
+            touched_max = 2 * (1 + W + K - 1)  # at most V = 2 new landmarks per step since step 1
+            active = {"value": acorr / awall, "unit": "update steps/s", "ms_per_step": awall / K * 1e3,
+                      "touched_landmarks_upper_bound": touched_max,
+                      "declared_bytes_per_correction_upper_bound": 16.0 * N * (3 + 2 * touched_max),
+                      "rank2_share_of_time": sa["rank2_ms"] / sa["elapsed_ms"],
+                      "speedup_vs_eager": (acorr / awall) / (corr / wall),
+                      "bit_identical_to_eager": bool(all(np.array_equal(x, y) for x, y in zip(astate, eager_state))),
+                      "note": "workload-dependent: rows of never-corrected landmarks have K = 0 exactly and are "
+                              "skipped; with every landmark corrected it degenerates to the dense stream"}
+        bt.set_active_set(False)
+
     if rank == 0:
         r2_avg_s = st["rank2_ms"] / max(st["rank2_launches"], 1) * 1e-3
         achieved = st["rank2_bytes_per_launch"] / r2_avg_s / 1e9
@@ -202,6 +232,8 @@ def main():
         }
         if delayed is not None:
             out["delayed_update"] = delayed
+        if active is not None:
+            out["active_set_update"] = active
         if not a.host_log:
             # Monte-Carlo consistency of the batch against the simulated ground truth (f4)
             out["mc_consistency"] = bt.mc_stats(T - 1)

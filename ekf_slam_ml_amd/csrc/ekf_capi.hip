@@ -6,6 +6,7 @@
 #include "ekf_dense.hpp"
 #include "ekf_sim.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -127,6 +128,10 @@ struct Pool {
     int active_prefix = 1;  // data_association(): restrict corrections to the discovered prefix of the state
     int touched_hwm = 0;    // landmarks [0, touched_hwm) may carry non-constructor covariance (single filter)
     int small_path = 1;     // measurement() of a small map runs as one LDS-resident launch (ekf_small.hip)
+    int active_set = 0;     // eager corrections stream only the rows of the touched set (opt-in)
+    int touched_bound = 0;  // host-side upper bound of the device touch_count over the pool
+    std::vector<unsigned char> host_touched;  // single filter: exact host copy of the touched flags
+    std::vector<int> log_touch_bound;         // batch: bound after step t of the uploaded log
     unsigned char* visible_dev = nullptr;  // [n] (single filter)
 
     ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count, pend_symmetric}; }
@@ -171,9 +176,36 @@ struct Pool {
         } else {
             EKFC(flush());
             ekf::launch_gain(pv, src, stream);
-            ekf::launch_rank2(pv, tuning, stream);
+            if (active_set) ekf::launch_rank2_active(pv, tuning, touched_bound, stream);
+            else ekf::launch_rank2(pv, tuning, stream);
         }
         return EKF_OK;
+    }
+
+    // single filter: landmark lm is about to be corrected
+    void note_touched(int lm) {
+        if (host_touched.size() != (size_t)pv.n) host_touched.assign(pv.n, 0);
+        if (lm >= 0 && lm < pv.n && !host_touched[lm]) { host_touched[lm] = 1; touched_bound++; }
+        if (touched_bound > pv.n) touched_bound = pv.n;
+    }
+
+    // batch: bound of the touched-set size after every step of a known-association log
+    void compute_log_touch_bound(const int* lm_idx, int T, int vmax) {
+        const int B = pv.B, n = pv.n;
+        std::vector<unsigned char> seen((size_t)B * (n > 0 ? n : 1), 0);
+        std::vector<int> cnt(B, 0);
+        log_touch_bound.assign(T, 0);
+        int best = 0;
+        for (int t = 0; t < T; t++) {
+            for (int b = 0; b < B; b++)
+                for (int v = 0; v < vmax; v++) {
+                    const int lm = lm_idx[((size_t)t * B + b) * vmax + v];
+                    if (lm < 0 || lm >= n) continue;
+                    unsigned char& sflag = seen[(size_t)b * n + lm];
+                    if (!sflag) { sflag = 1; if (++cnt[b] > best) best = cnt[b]; }
+                }
+            log_touch_bound[t] = best;
+        }
     }
 
     ekf_status use() {
@@ -218,6 +250,9 @@ struct Pool {
         EKFC(dalloc(&pv.snap, (size_t)B * 4));
         EKFC(dalloc(&pv.rec, (size_t)B));
         EKFC(dalloc(&pv.assoc, (size_t)B));
+        EKFC(dalloc(&pv.touch_flag, (size_t)B * (n > 0 ? n : 1)));
+        EKFC(dalloc(&pv.touch_list, (size_t)B * (n > 0 ? n : 1)));
+        EKFC(dalloc(&pv.touch_count, (size_t)B));
         EKFC(dalloc(&scores, (size_t)B * (n > 0 ? n : 1)));
         EKFC(dalloc(&digest_dev, (size_t)B * 4));
         EKFC(dalloc(&poses_dev, (size_t)B * 3));
@@ -230,6 +265,8 @@ struct Pool {
         EKFC(use());
         pend_count = 0;  // pending factors of the old run are dropped with it
         touched_hwm = 0;
+        touched_bound = 0;
+        std::fill(host_touched.begin(), host_touched.end(), 0);
         ekf::launch_init(pv, stream);
         HIPC(hipGetLastError());
         init_flag = 0;
@@ -239,7 +276,8 @@ struct Pool {
     void destroy() {
         if (device >= 0) (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, scores, meas_dev,
+        void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, pv.touch_flag, pv.touch_list,
+                        pv.touch_count, scores, meas_dev,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, log_truth};
         for (void* p : ptrs)
@@ -314,6 +352,9 @@ struct Pool {
         EKFC(use());
         EKFC(flush());
         touched_hwm = pv.n;  // caller-supplied covariance: no structure may be assumed any more
+        touched_bound = pv.n;
+        std::fill(host_touched.begin(), host_touched.end(), 1);
+        ekf::launch_touch_all(pv, stream);
         const size_t w = sizeof(double) * pv.N;
         Staging& sg = stage_in.acquire();
         EKFC(sg.reserve(w * pv.N));
@@ -428,6 +469,12 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
     c.tuning = a.tuning;
     c.touched_hwm = a.touched_hwm;
     c.small_path = a.small_path;
+    c.active_set = a.active_set;
+    c.touched_bound = a.touched_bound;
+    c.host_touched = a.host_touched;
+    HIPC(hipMemcpyAsync(c.pv.touch_flag, a.pv.touch_flag, (size_t)(a.pv.n > 0 ? a.pv.n : 1), hipMemcpyDeviceToDevice, c.stream));
+    HIPC(hipMemcpyAsync(c.pv.touch_list, a.pv.touch_list, sizeof(int) * (size_t)(a.pv.n > 0 ? a.pv.n : 1), hipMemcpyDeviceToDevice, c.stream));
+    HIPC(hipMemcpyAsync(c.pv.touch_count, a.pv.touch_count, sizeof(int), hipMemcpyDeviceToDevice, c.stream));
     c.active_prefix = a.active_prefix;
     return c.sync();
 }
@@ -452,6 +499,8 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
         P.init_flag = 1;
         for (int i = n - 1; i >= 0; i--)
             if (visible[i]) { if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1; break; }
+        for (int i = 0; i < n; i++)
+            if (visible[i]) P.note_touched(i);
         return checked_launch();
     }
     // ekf_slam.cpp:109-128.  The pose capture needs its own launch only together with the first-call
@@ -467,6 +516,7 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     for (int i = 0; i < n; i++) {  // ekf_slam.cpp:132-194, ascending landmark order
         if (!visible[i]) continue;
         if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1;
+        P.note_touched(i);
         src.lm_imm = i;
         src.fresh_pose = first ? 1 : 0;
         src.write_snap = first ? 1 : 0;
@@ -518,6 +568,9 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     EKFC(P.download(&rec, P.pv.assoc, sizeof(rec)));
     for (int i = known_count; i < rec.known_count && i < n; i++) known[i] = 1;  // :323
     if (rec.known_count > P.touched_hwm) P.touched_hwm = rec.known_count < n ? rec.known_count : n;
+    // for the host-side bound every landmark below the new known_count counts as touched (a superset
+    // of what this call's decisions actually corrected)
+    for (int i = 0; i < rec.known_count && i < n; i++) P.note_touched(i);
     if (assoc_out) EKFC(P.download(assoc_out, P.assoc_out_dev, sizeof(int) * J));
     return EKF_OK;
 }
@@ -580,6 +633,16 @@ ekf_status ekf_get_init_flag(ekf_handle h, int* flag) {
 ekf_status ekf_set_init_flag(ekf_handle h, int flag) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     h->pool.init_flag = flag ? 1 : 0;
+    return EKF_OK;
+}
+ekf_status ekf_set_active_set(ekf_handle h, int enable) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    h->pool.active_set = enable ? 1 : 0;
+    return EKF_OK;
+}
+ekf_status ekf_batch_set_active_set(ekf_batch_handle hb, int enable) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    hb->pool.active_set = enable ? 1 : 0;
     return EKF_OK;
 }
 ekf_status ekf_set_small_map_path(ekf_handle h, int enable) {
@@ -701,6 +764,9 @@ ekf_status ekf_batch_simulate_known_log(ekf_batch_handle hb, const ekf_sim_param
         HIPC(hipMemcpyAsync(active.data(), d_active, sizeof(int) * n_act, hipMemcpyDeviceToHost, P.stream));
         HIPC(hipStreamSynchronize(P.stream));
         P.slot_active.swap(active);
+        std::vector<int> lm_host(n_lm ? n_lm : 1, -1);
+        if (n_lm) HIPC(hipMemcpy(lm_host.data(), P.log_lm, sizeof(int) * n_lm, hipMemcpyDeviceToHost));
+        P.compute_log_touch_bound(lm_host.data(), T, vmax);
         return EKF_OK;
     };
     st = body();
@@ -798,6 +864,7 @@ ekf_status ekf_batch_upload_known_log(ekf_batch_handle hb, const ekf_known_log* 
     P.T = T;
     P.vmax = vmax;
     P.slot_active.swap(active);
+    P.compute_log_touch_bound(log->lm_idx, T, vmax);
     return EKF_OK;
 }
 
@@ -844,6 +911,8 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
         P.init_flag = 1;
         src.lm_idx = P.log_lm + (size_t)t * B * vmax;
         src.z_xy = P.log_z + (size_t)t * B * vmax * 2;
+        if ((size_t)t < P.log_touch_bound.size() && P.log_touch_bound[t] > P.touched_bound)
+            P.touched_bound = P.log_touch_bound[t];
         for (int v = 0; v < vmax; v++) {
             if (P.slot_active[(size_t)t * vmax + v] == 0) continue;
             src.v = v;
@@ -853,7 +922,8 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
             } else {
                 ekf::launch_gain(P.pv, src, P.stream);
                 if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
-                ekf::launch_rank2(P.pv, P.tuning, P.stream);
+                if (P.active_set) ekf::launch_rank2_active(P.pv, P.tuning, P.touched_bound, P.stream);
+                else ekf::launch_rank2(P.pv, P.tuning, P.stream);
                 if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
                 k++;
             }

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
             CorrRec rcd;
             rcd.nu0 = sh_nu[0]; rcd.nu1 = sh_nu[1]; rcd.active = 1; rcd.lm = lm;
             pv.rec[b] = rcd;
+            touch_landmark(pv, b, lm);
         }
     }
     __syncthreads();

@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256) void k_init(PoolView pv) {
             pv.Gh[(size_t)b * 2 * pv.ld + pv.ld + i] = 0.0;
         }
         if (threadIdx.x < 4) pv.snap[(size_t)b * 4 + threadIdx.x] = 0.0;
+        for (int i = threadIdx.x; i < pv.n; i += 256) pv.touch_flag[(size_t)b * pv.n + i] = 0;
         if (threadIdx.x == 0) {
             pv.rec[b] = CorrRec{0.0, 0.0, 0, -1};
             pv.assoc[b] = AssocRec{0, -1, 0, 0, 0.0};
+            pv.touch_count[b] = 0;
         }
     }
 }
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
             rc.active = 1;
             rc.lm = lm;
             pv.rec[b] = rc;
+            touch_landmark(pv, b, lm);
         }
     }
     __syncthreads();
@@ -419,6 +422,71 @@ __global__ __launch_bounds__(256) void k_rank2(double* __restrict__ sigma, const
             st[rr] = s;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Active-set form of the same update (opt-in, reported separately): only the rows of the touched set
+// -- pose rows and the rows of landmarks that have ever been corrected -- can have K != 0, so only they
+// are streamed: 2*8*N*(3 + 2*touched) bytes instead of 2*8*N^2.  Bit-identical to k_rank2 for finite
+// states.  A workgroup owns a strip of 256 double2 columns and rows_per_block SLOTS of the row list.
+// grid (strips, ceil((3 + 2*max_touched)/rows_per_block), B).
+// ---------------------------------------------------------------------------------------------
+template <bool NT>
+__global__ __launch_bounds__(256) void k_rank2_active(PoolView pv, int rows_per_block) {
+    const int b = blockIdx.z;
+    if (!pv.rec[b].active) return;
+    const int N = pv.N, ld = pv.ld, ld2n = ld >> 1, ld2a = (N + 1) >> 1;
+    const int nslots = 3 + 2 * pv.touch_count[b];
+    const int s0 = blockIdx.y * rows_per_block;
+    if (s0 >= nslots) return;
+    const int s1 = min(nslots, s0 + rows_per_block);
+    const int* __restrict__ list = pv.touch_list + (size_t)b * pv.n;
+    auto slot_row = [&](int s) { return s < 3 ? s : 3 + 2 * list[(s - 3) >> 1] + ((s - 3) & 1); };
+    const double2_t* __restrict__ Kg = reinterpret_cast<const double2_t*>(pv.Kg + (size_t)b * 2 * ld);
+    const int c2 = blockIdx.x * 256 + threadIdx.x;
+    if (c2 < ld2a) {
+        const double2_t g0 = reinterpret_cast<const double2_t*>(pv.Gh + (size_t)b * 2 * ld)[c2];
+        const double2_t g1 = reinterpret_cast<const double2_t*>(pv.Gh + (size_t)b * 2 * ld + ld)[c2];
+        double2_t* col = reinterpret_cast<double2_t*>(pv.sigma + (size_t)b * pv.sigma_stride) + c2;
+        constexpr int U = 8;
+        for (int s = s0; s < s1; s += U) {
+            int rows[U];
+            double2_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                rows[u] = s + u < s1 ? slot_row(s + u) : -1;
+                if (rows[u] >= 0) v[u] = ld2<NT>(col + (size_t)rows[u] * ld2n);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (rows[u] >= 0) {
+                    const double2_t k = Kg[rows[u]];
+                    v[u].x = v[u].x - (k.x * g0.x + k.y * g1.x);
+                    v[u].y = v[u].y - (k.x * g0.y + k.y * g1.y);
+                    st2<NT>(col + (size_t)rows[u] * ld2n, v[u]);
+                }
+        }
+    }
+    if (blockIdx.x == 0) {  // state = state + Ki*z_diff (:186), theta wrap (:187), touched rows only
+        const CorrRec rc = pv.rec[b];
+        double* st = pv.state + (size_t)b * ld;
+        for (int s = s0 + (int)threadIdx.x; s < s1; s += 256) {
+            const int rr = slot_row(s);
+            const double2_t k = Kg[rr];
+            double sv = st[rr] + (k.x * rc.nu0 + k.y * rc.nu1);
+            if (rr == 0) sv = normalize_angle(sv);
+            st[rr] = sv;
+        }
+    }
+}
+
+__global__ void k_touch_all(PoolView pv) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < pv.n; i += blockDim.x) {
+        pv.touch_flag[(size_t)b * pv.n + i] = 1;
+        pv.touch_list[(size_t)b * pv.n + i] = i;
+    }
+    if (threadIdx.x == 0) pv.touch_count[b] = pv.n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -633,6 +701,20 @@ void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s) {
         case 16: launch_rank2_u<16>(pv, rows, nt, s); break;
         default: launch_rank2_u<8>(pv, rows, nt, s); break;
     }
+}
+
+void launch_rank2_active(const PoolView& pv, const Rank2Tuning& t, int max_touched, hipStream_t s) {
+    const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
+    const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
+    const int rows = 8;
+    const int nslots = 3 + 2 * (max_touched < pv.n ? max_touched : pv.n);
+    dim3 grid(((pv.N + 1) / 2 + 255) / 256, (nslots + rows - 1) / rows, pv.B);
+    if (nt) hipLaunchKernelGGL((k_rank2_active<true>), grid, dim3(256), 0, s, pv, rows);
+    else hipLaunchKernelGGL((k_rank2_active<false>), grid, dim3(256), 0, s, pv, rows);
+}
+
+void launch_touch_all(const PoolView& pv, hipStream_t s) {
+    hipLaunchKernelGGL(k_touch_all, dim3(pv.B), dim3(256), 0, s, pv);
 }
 
 void launch_maha(const PoolView& pv, const double* meas, double* scores, int m_override, hipStream_t s) {

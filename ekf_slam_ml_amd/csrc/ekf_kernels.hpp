@@ -84,10 +84,27 @@ struct PoolView {
     double* snap;
     CorrRec* rec;
     AssocRec* assoc;
+    // Touched set: landmarks that have ever been corrected, in first-touch order.  Rows/columns of every
+    // other landmark still hold their constructor values and are decoupled from everything (exact zeros
+    // off the diagonal), so K(r,:) and (H Sigma)(:,c) are exact zeros there: a correction is a no-op on them.
+    unsigned char* touch_flag;  // [B][n]
+    int* touch_list;            // [B][n]
+    int* touch_count;           // [B]
     int n, N, ld, B;
     size_t sigma_stride;  // doubles between consecutive filters' covariances = N * ld
     Params p;
 };
+
+// called by ONE lane per filter and correction
+__device__ __forceinline__ void touch_landmark(const PoolView& pv, int b, int lm) {
+    unsigned char* tf = pv.touch_flag + (size_t)b * pv.n;
+    if (!tf[lm]) {
+        tf[lm] = 1;
+        const int c = pv.touch_count[b];
+        pv.touch_list[(size_t)b * pv.n + c] = lm;
+        pv.touch_count[b] = c + 1;
+    }
+}
 
 // rigid2d/src/rigid2d.cpp:336-345 -- double-fmod form, range (-pi, pi]
 __device__ __forceinline__ double normalize_angle(double rad) {
@@ -171,6 +188,10 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
 void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init, hipStream_t s);
 void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s);
 void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s);
+// Same update restricted to the rows of the touched set (exact: every other row has K = 0).
+// max_touched: host-side upper bound of touch_count over the pool (sizes the grid).
+void launch_rank2_active(const PoolView& pv, const Rank2Tuning& t, int max_touched, hipStream_t s);
+void launch_touch_all(const PoolView& pv, hipStream_t s);  // marks every landmark touched (after set_cov)
 // data_association(): scores for landmarks [0, known_count) of every filter, one landmark per wavefront
 void launch_maha(const PoolView& pv, const double* meas /*[B][2]*/, double* scores /*[B][n]*/, int m_override,
                  hipStream_t s);

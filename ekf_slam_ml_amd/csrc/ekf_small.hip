@@ -63,6 +63,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_measure(PoolView pv, co
             sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
             sh_nu[0] = m.z0 - m.zh0;                   // :182
             sh_nu[1] = normalize_angle(m.z1 - m.zh1);  // :183
+            touch_landmark(pv, b, lm);
         }
         __syncthreads();
         double k0 = 0.0, k1 = 0.0;

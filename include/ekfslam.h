@@ -104,6 +104,13 @@ ekf_status ekf_set_init_flag(ekf_handle h, int flag);
  * leading (3 + 2*known_count) block of the state; enable != 0 (default) streams only that block. Results are
  * bit-identical to enable == 0 for finite states. */
 ekf_status ekf_set_active_prefix(ekf_handle h, int enable);
+/* Active-set covariance update (opt-in, default 0; reported separately from the dense contract path):
+ * the eager correction streams only the rows of the TOUCHED set -- the pose rows and the rows of landmarks
+ * that have ever been corrected.  Every other row has K(r,:) = 0 exactly (its landmark still carries the
+ * constructor covariance and is decoupled from everything), so the result is bit-identical for finite
+ * states while the traffic drops from 2*8*N^2 to 2*8*N*(3 + 2*touched) bytes per correction. */
+ekf_status ekf_set_active_set(ekf_handle h, int enable);
+ekf_status ekf_batch_set_active_set(ekf_batch_handle hb, int enable);
 /* Small maps (N = 3 + 2n <= 104, e.g. the reference's n = 20): measurement() runs as ONE single-workgroup,
  * LDS-resident launch instead of 2 launches per visible landmark; enable != 0 is the default.  Bit-identical
  * to the multi-kernel path. */

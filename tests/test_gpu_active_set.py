@@ -1,0 +1,82 @@
+"""-m gpu: active-set covariance update (opt-in): the eager correction streams only the rows of the
+touched set.  Must be BIT-identical to the dense path (every skipped row has K = 0 exactly)."""
+import numpy as np
+import pytest
+
+from ekf_slam_ml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_filter_active_set_bitwise(hip):
+    log = synth.make_known_log(synth.config2(steps=40))
+    outs = []
+    for on in (False, True):
+        f = hip.EKF_SLAM(200)
+        f.set_active_set(on)
+        for t in range(40):
+            sensor, vis = log.expand_step(t)
+            f.prediction(log.twist[t, 0]); f.measurement(sensor, vis)
+            if t == 20:   # interleave an association call and a clone: the touched set must follow
+                k = np.ones(200, dtype=np.uint8)
+                f.data_association(log.z_xy[t, 0, :2], k)
+                g = f.clone(); f.close(); f = g
+        outs.append((f.state, f.cov))
+        f.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_set_cov_marks_everything_touched(hip):
+    rng = np.random.default_rng(2)
+    n = 30
+    a = rng.normal(size=(3 + 2 * n, 3 + 2 * n))
+    cov = a @ a.T + np.eye(3 + 2 * n)                 # fully dense covariance supplied by the caller
+    st = rng.normal(size=3 + 2 * n)
+    sensor = rng.normal(size=2 * n) + 2.0
+    outs = []
+    for on in (False, True):
+        f = hip.EKF_SLAM(n)
+        f.set_small_map_path(False)
+        f.set_active_set(on)
+        f.state, f.cov = st, cov
+        f.landmark_init_flag = True
+        vis = np.zeros(n, dtype=np.uint8); vis[[3, 7, 19]] = 1
+        f.prediction((0.1, 0.05))
+        f.measurement(sensor, vis)
+        outs.append((f.state, f.cov))
+        f.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_batch_active_set_bitwise_n1000(hip):
+    cfg = synth.config5(filters=10, steps=12, n=1000)
+    log = synth.make_known_log(cfg)
+    res = []
+    for on in (False, True):
+        bt = hip.BatchEKF(10, 1000)
+        bt.set_active_set(on)
+        bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+        bt.run_known(0, 5)
+        st = bt.run_known(5, 12, time_kernels=True)
+        res.append(([bt.state(b) for b in range(10)], [bt.cov(b) for b in (0, 4, 9)], bt.checksum(), st))
+        bt.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)
+    assert res[1][3]["rank2_ms"] < res[0][3]["rank2_ms"]   # and it must actually be cheaper
+
+
+def test_batch_active_set_with_device_generated_log(hip):
+    cfg = synth.config5(filters=9, steps=10, n=400)
+    world = synth.make_world(cfg.n, cfg.half_extent, cfg.min_spacing, cfg.world_seed)
+    res = []
+    for on in (False, True):
+        bt = hip.BatchEKF(9, 400)
+        bt.set_active_set(on)
+        bt.simulate_known_log(cfg, world)
+        bt.run_known()
+        res.append([(bt.state(b), bt.cov(b)) for b in range(9)])
+        bt.close()
+    for (s0, c0), (s1, c1) in zip(*res):
+        assert np.array_equal(s0, s1) and np.array_equal(c0, c1)
