@@ -25,7 +25,7 @@ _fp = C.POINTER(C.c_float)
 STATUS = {0: "EKF_OK", 1: "EKF_ERR_INVALID", 2: "EKF_ERR_NO_DEVICE", 3: "EKF_ERR_HIP", 4: "EKF_ERR_NOMEM",
           5: "EKF_ERR_STATE"}
 
-# every symbol include/ekfslam.h declares (tests/test_capi_symbols.py checks the .so exports them all)
+# every symbol include/ekfslam.h declares (tests/test_host.py checks the .so exports them all)
 SYMBOLS = [
     "ekf_last_error", "ekf_default_params", "ekf_device_count",
     "ekf_create", "ekf_destroy", "ekf_clone", "ekf_predict", "ekf_measure_known", "ekf_associate",
