@@ -87,3 +87,25 @@ def test_single_filter_n1000_unknown_association(hip, oracle):
     want = np.array([o.maha(*log.meas_xy[24, 0, 0], i) for i in range(int(kf.sum()))])
     assert np.abs(sc - want).max() / np.abs(want).max() < FP64_TOL
     f.close()
+
+
+def test_largest_map_n5000(hip, oracle):
+    """Maximum size of BASELINE.json (n = 5000, N = 10003, 800 MB of covariance per filter): the filter
+    kernels (not only the dense propagation) against the structured checker, eager and delayed."""
+    n = 5000
+    cfg = synth.SimConfig(n=n, steps=4, filters=1, seed=50, half_extent=30.0, min_spacing=0.5, v_cmd=0.5, w_cmd=0.05,
+                          max_visible_dis=1e9, vmax=3)
+    log = synth.make_known_log(cfg)
+    o = oracle.OracleEKF(n, oracle.STRUCTURED)
+    for t in range(4):
+        o.prediction(*log.twist[t, 0])
+        o.measurement_compact(log.init_xy[0], log.lm_idx[t, 0], log.z_xy[t, 0])
+    ocov = o.cov
+    for k in (0, 4):
+        f = hip.EKF_SLAM(n)
+        f.set_update_mode(k)
+        for t in range(4):
+            sensor, vis = log.expand_step(t)
+            f.prediction(log.twist[t, 0]); f.measurement(sensor, vis)
+        assert_parity(f.state, f.cov, o.state, ocov, FP64_TOL, f"n=5000 update mode {k}")
+        f.close()
