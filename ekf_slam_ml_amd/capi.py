@@ -30,7 +30,7 @@ SYMBOLS = [
     "ekf_last_error", "ekf_default_params", "ekf_device_count",
     "ekf_create", "ekf_destroy", "ekf_clone", "ekf_predict", "ekf_measure_known", "ekf_associate",
     "ekf_maha_scores", "ekf_get_pose", "ekf_get_landmarks", "ekf_dim", "ekf_get_state", "ekf_set_state",
-    "ekf_get_cov", "ekf_set_cov", "ekf_get_init_flag", "ekf_set_init_flag", "ekf_sync", "ekf_set_tuning", "ekf_set_active_prefix", "ekf_set_small_map_path", "ekf_set_active_set", "ekf_batch_set_active_set",
+    "ekf_get_cov", "ekf_set_cov", "ekf_get_init_flag", "ekf_set_init_flag", "ekf_sync", "ekf_set_tuning", "ekf_set_active_prefix", "ekf_set_small_map_path", "ekf_set_active_set", "ekf_batch_set_active_set", "ekf_batch_get_touched",
     "ekf_batch_create", "ekf_batch_destroy", "ekf_batch_reset", "ekf_batch_device_bytes",
     "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_get_state", "ekf_batch_get_cov",
     "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
@@ -116,6 +116,7 @@ def load():
         "ekf_set_small_map_path": [h, C.c_int],
         "ekf_set_active_set": [h, C.c_int],
         "ekf_batch_set_active_set": [h, C.c_int],
+        "ekf_batch_get_touched": [h, _ip],
         "ekf_set_tuning": [h, C.c_int, C.c_int, C.c_int],
         "ekf_batch_create": [C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.POINTER(h)],
         "ekf_batch_destroy": [h],
@@ -402,6 +403,12 @@ class BatchEKF:
     def set_active_set(self, enable=True):
         """Stream only the rows of the touched set in the eager correction (exact; opt-in)."""
         _check(self._lib.ekf_batch_set_active_set(self._h, int(bool(enable))))
+
+    def touched(self):
+        """Per filter: how many landmarks have been corrected at least once."""
+        out = np.zeros(self.B, dtype=np.int32)
+        _check(self._lib.ekf_batch_get_touched(self._h, out.ctypes.data_as(_ip)))
+        return out
 
     def set_update_mode(self, max_pending_corrections=0, symmetric_gather=False):
         """0 = eager covariance stream per correction; k > 0 = delayed rank-2k update (flush every k)."""

@@ -470,6 +470,7 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
     c.touched_hwm = a.touched_hwm;
     c.small_path = a.small_path;
     c.active_set = a.active_set;
+    c.pv.active_set = a.active_set;
     c.touched_bound = a.touched_bound;
     c.host_touched = a.host_touched;
     HIPC(hipMemcpyAsync(c.pv.touch_flag, a.pv.touch_flag, (size_t)(a.pv.n > 0 ? a.pv.n : 1), hipMemcpyDeviceToDevice, c.stream));
@@ -638,12 +639,19 @@ ekf_status ekf_set_init_flag(ekf_handle h, int flag) {
 ekf_status ekf_set_active_set(ekf_handle h, int enable) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     h->pool.active_set = enable ? 1 : 0;
+    h->pool.pv.active_set = h->pool.active_set;
     return EKF_OK;
 }
 ekf_status ekf_batch_set_active_set(ekf_batch_handle hb, int enable) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
     hb->pool.active_set = enable ? 1 : 0;
+    hb->pool.pv.active_set = hb->pool.active_set;
     return EKF_OK;
+}
+ekf_status ekf_batch_get_touched(ekf_batch_handle hb, int* counts_out) {
+    if (!hb || !counts_out) return fail(EKF_ERR_INVALID, "null argument");
+    EKFC(hb->pool.use());
+    return hb->pool.download(counts_out, hb->pool.pv.touch_count, sizeof(int) * hb->pool.pv.B);
 }
 ekf_status ekf_set_small_map_path(ekf_handle h, int enable) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");

@@ -72,10 +72,15 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
     // trigonometry and fly under it.
     constexpr int PRE = 2;
     double s0[PRE], s1[PRE], s2[PRE], r0[PRE], r1[PRE], r2[PRE];
+    // active-set mode: row/column k of a never-corrected landmark is exactly zero against the pose block,
+    // so its update a*0 + 0 = 0 is skipped (bit-identical)
+    const unsigned char* tf = pv.touch_flag + (size_t)b * pv.n;
+    bool live[PRE];
 #pragma unroll
     for (int q = 0; q < PRE; q++) {
         const int k = 3 + (int)threadIdx.x + q * kPredictThreads;
-        if (k < N) {
+        live[q] = k < N && (!pv.active_set || tf[(k - 3) >> 1]);
+        if (live[q]) {
             s0[q] = Sg[k];                      // row 0 (coalesced)
             s1[q] = Sg[(size_t)1 * ld + k];
             s2[q] = Sg[(size_t)2 * ld + k];
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
 #pragma unroll
     for (int q = 0; q < PRE; q++) {
         const int k = 3 + (int)threadIdx.x + q * kPredictThreads;
-        if (k < N) {
+        if (live[q]) {
             double* rowk = Sg + (size_t)k * ld;
             Sg[(size_t)1 * ld + k] = a10 * s0[q] + s1[q];
             Sg[(size_t)2 * ld + k] = a20 * s0[q] + s2[q];
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
         }
     }
     for (int k = 3 + threadIdx.x + PRE * kPredictThreads; k < N; k += kPredictThreads) {
+        if (pv.active_set && !tf[(k - 3) >> 1]) continue;
         const double t0 = Sg[k];
         const double t1 = Sg[(size_t)1 * ld + k];
         const double t2 = Sg[(size_t)2 * ld + k];
@@ -235,12 +241,16 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
     // block, and -- on lane 0 -- the pose and the landmark.
     const int r = blockIdx.x * 256 + tid;
     double p[5], g[5];
+    // active-set mode: a row of a never-corrected landmark (other than lm itself) has Sigma(r, c5) = 0 exactly,
+    // hence K(r,:) = 0: the 16-KB-strided column gather is skipped for it (bit-identical downstream)
+    const bool krow = r < N && (!pv.active_set || r < 3 || ((r - 3) >> 1) == lm ||
+                                pv.touch_flag[(size_t)b * pv.n + ((r - 3) >> 1)]);
     if (r < N) {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int c = idx5(k, lm);
-            p[k] = Sg[(size_t)r * ld + c];  // column gather (Sigma * H^T reads columns)
-            g[k] = Sg[(size_t)c * ld + r];  // row gather    (H * Sigma reads rows)
+            p[k] = krow ? Sg[(size_t)r * ld + c] : 0.0;  // column gather (Sigma * H^T reads columns)
+            g[k] = Sg[(size_t)c * ld + r];               // row gather    (H * Sigma reads rows)
         }
     }
     if (tid < 25) sh_S55[tid] = Sg[(size_t)idx5(tid / 5, lm) * ld + idx5(tid % 5, lm)];

@@ -90,6 +90,7 @@ struct PoolView {
     unsigned char* touch_flag;  // [B][n]
     int* touch_list;            // [B][n]
     int* touch_count;           // [B]
+    int active_set;             // 1: kernels may skip the rows/columns of untouched landmarks (exact)
     int n, N, ld, B;
     size_t sigma_stride;  // doubles between consecutive filters' covariances = N * ld
     Params p;

@@ -111,6 +111,8 @@ ekf_status ekf_set_active_prefix(ekf_handle h, int enable);
  * states while the traffic drops from 2*8*N^2 to 2*8*N*(3 + 2*touched) bytes per correction. */
 ekf_status ekf_set_active_set(ekf_handle h, int enable);
 ekf_status ekf_batch_set_active_set(ekf_batch_handle hb, int enable);
+/* Size of every filter's touched set (landmarks corrected at least once): counts_out[B]. */
+ekf_status ekf_batch_get_touched(ekf_batch_handle hb, int* counts_out);
 /* Small maps (N = 3 + 2n <= 104, e.g. the reference's n = 20): measurement() runs as ONE single-workgroup,
  * LDS-resident launch instead of 2 launches per visible landmark; enable != 0 is the default.  Bit-identical
  * to the multi-kernel path. */
