@@ -132,6 +132,7 @@ struct Pool {
     int touched_bound = 0;  // host-side upper bound of the device touch_count over the pool
     std::vector<unsigned char> host_touched;  // single filter: exact host copy of the touched flags
     std::vector<int> log_touch_bound;         // batch: bound after step t of the uploaded log
+    int touch_bound_base = 0;                 // touched_bound when that log arrived (filters may not be fresh)
     unsigned char* visible_dev = nullptr;  // [n] (single filter)
 
     ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count, pend_symmetric}; }
@@ -195,6 +196,7 @@ struct Pool {
         std::vector<unsigned char> seen((size_t)B * (n > 0 ? n : 1), 0);
         std::vector<int> cnt(B, 0);
         log_touch_bound.assign(T, 0);
+        touch_bound_base = touched_bound;  // |old set UNION new landmarks| <= old bound + new count
         int best = 0;
         for (int t = 0; t < T; t++) {
             for (int b = 0; b < B; b++)
@@ -266,6 +268,7 @@ struct Pool {
         pend_count = 0;  // pending factors of the old run are dropped with it
         touched_hwm = 0;
         touched_bound = 0;
+        touch_bound_base = 0;
         std::fill(host_touched.begin(), host_touched.end(), 0);
         ekf::launch_init(pv, stream);
         HIPC(hipGetLastError());
@@ -919,8 +922,11 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
         P.init_flag = 1;
         src.lm_idx = P.log_lm + (size_t)t * B * vmax;
         src.z_xy = P.log_z + (size_t)t * B * vmax * 2;
-        if ((size_t)t < P.log_touch_bound.size() && P.log_touch_bound[t] > P.touched_bound)
-            P.touched_bound = P.log_touch_bound[t];
+        if ((size_t)t < P.log_touch_bound.size()) {
+            int cand = P.touch_bound_base + P.log_touch_bound[t];
+            if (cand > P.pv.n) cand = P.pv.n;
+            if (cand > P.touched_bound) P.touched_bound = cand;
+        }
         for (int v = 0; v < vmax; v++) {
             if (P.slot_active[(size_t)t * vmax + v] == 0) continue;
             src.v = v;

@@ -80,3 +80,26 @@ def test_batch_active_set_with_device_generated_log(hip):
         bt.close()
     for (s0, c0), (s1, c1) in zip(*res):
         assert np.array_equal(s0, s1) and np.array_equal(c0, c1)
+
+
+def test_second_log_on_used_filters(hip):
+    """A new log uploaded onto filters that already carry touched landmarks: the grid bound of the
+    active-set kernel must cover the union of old and new touched sets."""
+    cfg1 = synth.config5(filters=4, steps=6, n=300)
+    cfg2 = synth.config5(filters=4, steps=6, n=300)
+    cfg2.seed = 777                      # different noise, and ...
+    cfg2.v_cmd, cfg2.w_cmd = -0.8, 0.3   # ... a different path: other landmarks come into view
+    l1, l2 = synth.make_known_log(cfg1), synth.make_known_log(cfg2)
+    res = []
+    for on in (False, True):
+        bt = hip.BatchEKF(4, 300)
+        bt.set_active_set(on)
+        bt.upload_known_log(l1.twist, l1.lm_idx, l1.z_xy, l1.init_xy)
+        bt.run_known()
+        bt.upload_known_log(l2.twist, l2.lm_idx, l2.z_xy, l2.init_xy)   # no reset in between
+        bt.run_known()
+        res.append([(bt.state(b), bt.cov(b)) for b in range(4)] + [bt.touched()])
+        bt.close()
+    for b in range(4):
+        assert np.array_equal(res[0][b][0], res[1][b][0]) and np.array_equal(res[0][b][1], res[1][b][1])
+    assert np.array_equal(res[0][4], res[1][4]) and res[1][4].max() >= 3
