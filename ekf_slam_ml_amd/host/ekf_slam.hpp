@@ -162,4 +162,33 @@ private:
     }
 };
 
+// Mirror of rigid2d::CircleFitting's production entry point (rigid2d/include/rigid2d/circle_fitting.hpp:27,
+// rigid2d/src/circle_fitting.cpp:298-304): laser ranges in, centres of the clusters classified as circles out,
+// in cluster order -- what nuslam/src/landmarks.cpp:141 publishes as the scan_sensor markers.
+class CircleFitting {
+public:
+    explicit CircleFitting(int device = -1, int max_circles = 64) : dev(device), cap(max_circles) {}
+
+    template <class Vec2T = Vector2D>
+    std::vector<Vec2T> approxCirclePositions(std::vector<double> ranges) {
+        static_assert(std::is_standard_layout<Vec2T>::value && sizeof(Vec2T) == 2 * sizeof(double),
+                      "Vector2D must be two packed doubles {x, y} (rigid2d.hpp:68-72)");
+        std::vector<double> centres(static_cast<size_t>(cap) * 2), radii(static_cast<size_t>(cap));
+        int count = 0;
+        detail::check(ekf_circle_fit_scans(dev, ranges.data(), 1, static_cast<int>(ranges.size()), cap, centres.data(),
+                                           radii.data(), &count, nullptr, nullptr),
+                      "approxCirclePositions");
+        std::vector<Vec2T> out(static_cast<size_t>(count));
+        for (int i = 0; i < count; i++) { out[i].x = centres[2 * i]; out[i].y = centres[2 * i + 1]; }
+        r_cluster.assign(radii.begin(), radii.begin() + count);
+        return out;
+    }
+    /// radii of the circles returned by the last call (the reference keeps r_cluster for ALL clusters)
+    const std::vector<double>& get_r_circles() const { return r_cluster; }
+
+private:
+    int dev, cap;
+    std::vector<double> r_cluster;
+};
+
 }  // namespace ekfslam

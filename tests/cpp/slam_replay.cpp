@@ -45,6 +45,7 @@ struct SLAM {
     std::vector<double> sensor_reading;  // zeros<mat>(max_n_tubes*2, 1), slam.cpp:259
     std::vector<Vector2D> scan_measures;
     EKF_SLAM slam_agent;                 // by-value member, slam.cpp:213
+    ekfslam::CircleFitting circle_fitting;
 
     SLAM(int n, bool unknown, Odometer& odo)
         : max_n_tubes(n), unknown_assoc(unknown), odometer(odo), visible_list(n, false), known_list(n, false),
@@ -60,6 +61,13 @@ struct SLAM {
             }
         }
         sensor_update_flag = true;
+    }
+    // landmarks node (nuslam/src/landmarks.cpp:60-72,129-149): scan -> CircleFitting -> scan_sensor markers
+    void callback_scan(const std::vector<double>& ranges) {
+        std::vector<Vector2D> circles = circle_fitting.approxCirclePositions(ranges);
+        std::vector<Marker> ms;
+        for (size_t i = 0; i < circles.size(); i++) ms.push_back(Marker{(int)i, circles[i].x, circles[i].y, 1});
+        callback_scan_sensor(ms);
     }
     void callback_scan_sensor(const std::vector<Marker>& tubes) {  // unknown_data_assoc.cpp:309-320
         scan_measures.clear();
@@ -104,7 +112,11 @@ int main(int argc, char** argv) {
             std::vector<Marker> ms(count);
             for (Marker& m : ms)
                 if (std::fscanf(f, "%d %la %la %d", &m.id, &m.x, &m.y, &m.add) != 4) return 2;
-            if (unknown) node.callback_scan_sensor(ms);
+            if (unknown == 2) {  // markers carry raw laser ranges in .x: the landmarks node runs first
+                std::vector<double> ranges(ms.size());
+                for (size_t i = 0; i < ms.size(); i++) ranges[i] = ms[i].x;
+                node.callback_scan(ranges);
+            } else if (unknown) node.callback_scan_sensor(ms);
             else node.callback_fake_sensor(ms);
             node.main_loop();
             node.main_loop();  // a timer tick without new sensor data must be a no-op on the filter

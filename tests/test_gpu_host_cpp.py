@@ -78,3 +78,27 @@ def test_unknown_association_node_loop(hip, oracle, tmp_path):
     state, cov, known_cpp, _ = _run(tmp_path, lines, n)
     assert np.array_equal(known_cpp, known) and known.sum() >= 5
     assert_parity(state, cov, o.state, o.cov, FP64_TOL, "C++ node loop, unknown association")
+
+
+def test_scan_pipeline_node_loop(hip, oracle, tmp_path):
+    """landmarks node + unknown_data_assoc node in C++: laser ranges -> ekfslam::CircleFitting ->
+    EKF_SLAM::data_association, against the checker's circle fitting + filter."""
+    n, T = 10, 40
+    cfg = synth.config1(steps=T)
+    cfg.seed = 4711
+    log = synth.make_unknown_log(cfg)
+    world = np.stack([synth.TUBE_X, synth.TUBE_Y], axis=1)
+    scans = synth.make_scans(log.true_pose[:, 0], world=world, seed=12)
+    lines = [f"2 {n} {T} {_hex(synth.WHEEL_BASE)} {_hex(synth.WHEEL_RADIUS)}"]
+    o = oracle.OracleEKF(n, oracle.DENSE)
+    known = np.zeros(n, dtype=np.uint8)
+    for t in range(T):
+        lines.append(f"{_hex(log.wheel[t, 0, 0])} {_hex(log.wheel[t, 0, 1])} {scans.shape[1]}")
+        for i, r in enumerate(scans[t]):
+            lines.append(f"{i} {_hex(r)} {_hex(0.0)} 1")
+        circles, _, _ = oracle.approx_circle_positions(scans[t])
+        o.prediction(*log.twist[t, 0])
+        o.data_association(circles, known)
+    state, cov, known_cpp, _ = _run(tmp_path, lines, n)
+    assert np.array_equal(known_cpp, known) and known.sum() >= 3
+    assert_parity(state, cov, o.state, o.cov, FP64_TOL, "C++ scan -> circles -> association")
