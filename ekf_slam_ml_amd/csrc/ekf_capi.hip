@@ -543,6 +543,18 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     EKFC(P.flush());  // the scoring kernel reads Sigma directly
     EKFC(P.ensure_meas_capacity(J));
     EKFC(P.upload(P.meas_dev, meas_xy, sizeof(double) * 2 * J));
+    if (P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && n <= 128) {
+        // small map: scores, decisions and corrections of all J measurements in one LDS-resident launch
+        ekf::launch_small_associate(P.pv, P.meas_dev, J, known_count, P.assoc_out_dev, P.stream);
+        EKFC(checked_launch());
+        ekf::AssocRec rec_s;
+        EKFC(P.download(&rec_s, P.pv.assoc, sizeof(rec_s)));
+        for (int i = known_count; i < rec_s.known_count && i < n; i++) known[i] = 1;  // :323
+        if (rec_s.known_count > P.touched_hwm) P.touched_hwm = rec_s.known_count < n ? rec_s.known_count : n;
+        for (int i = 0; i < rec_s.known_count && i < n; i++) P.note_touched(i);
+        if (assoc_out) EKFC(P.download(assoc_out, P.assoc_out_dev, sizeof(int) * J));
+        return EKF_OK;
+    }
     ekf::launch_assoc_begin(P.pv, nullptr, known_count, P.stream);
     ekf::CmdSrc src{};
     src.mode = ekf::SRC_ASSOC;

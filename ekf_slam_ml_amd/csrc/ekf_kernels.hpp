@@ -211,6 +211,9 @@ int circles_max_clusters();
 // whole measurement() call of a SMALL map in one single-workgroup, LDS-resident launch (ekf_small.hip)
 void launch_small_measure(const PoolView& pv, const double* sensor, const unsigned char* visible, int do_init,
                           hipStream_t s);
+// whole data_association() call of a small map (single filter: pv.B == 1) in one launch
+void launch_small_associate(const PoolView& pv, const double* meas, int J, int known_count, int* assoc_out,
+                            hipStream_t s);
 int small_max_dim();          // largest N = 3 + 2n the small path accepts
 hipError_t small_prepare();   // raises the kernel's dynamic-LDS limit (87 KB > 64 KB default)
 int max_pending();  // capacity limit of the delayed-update factor store (rows of U / V per filter)

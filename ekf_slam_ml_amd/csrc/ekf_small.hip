@@ -102,12 +102,165 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_measure(PoolView pv, co
     for (int r = tid; r < N; r += kSmallThreads) stg[r] = st[r];
 }
 
+// ---------------------------------------------------------------------------------------------
+// data_association() of a small map in ONE launch (ekf_slam.cpp:278-402): for every measurement, in order,
+// the Mahalanobis scores of the known landmarks (one landmark per WAVEFRONT: the 25-lane gather and the
+// shuffle folds of k_maha, fed from LDS), the sequential-scan decision with its two gates and the
+// new-landmark initialisation (k_assoc_decide), and the correction with the fresh pose (k_gain + k_rank2).
+// Same arithmetic as the multi-kernel chain -> bit-identical results and decisions.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSmallThreads) void k_small_associate(PoolView pv, const double* __restrict__ meas, int J,
+                                                                   int known_count_in, int* __restrict__ assoc_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid / kWave, lane = tid % kWave;
+    const int N = pv.N, ld = pv.ld, n = pv.n;
+    const int ldS = N | 1;
+    double* S = sm;
+    double* st = S + (size_t)N * ldS;
+    double* Gg = st + N;
+    __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
+    __shared__ double sh_score[128];
+    __shared__ int sh_M, sh_lm;
+
+    double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    double* stg = pv.state + (size_t)b * ld;
+    for (int r = tid >> 6; r < N; r += kSmallThreads / 64)
+        for (int c = tid & 63; c < N; c += 64) S[r * ldS + c] = Sg[(size_t)r * ld + c];
+    for (int r = tid; r < N; r += kSmallThreads) st[r] = stg[r];
+    if (tid == 0) sh_M = known_count_in;
+    __syncthreads();
+
+    for (int j = 0; j < J; j++) {                       // :291 sequential, state-carrying
+        const double mx = meas[2 * j], my = meas[2 * j + 1];
+        const int M = sh_M;
+        for (int i = wave; i < M; i += kSmallThreads / kWave) {   // :300-309, one landmark per wavefront
+            double v = 0.0;
+            if (lane < 25) v = S[idx5(lane / 5, i) * ldS + idx5(lane % 5, i)];
+            MeasTerms m;                                 // fresh pose per score, :219-221
+            measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, st[0], st[1], st[2], m);
+            const int l5 = lane < 5 ? lane : 4;
+            double hs0 = 0.0, hs1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const double vk = __shfl(v, k * 5 + l5, kWave);
+                hs0 += m.H[0][k] * vk;
+                hs1 += m.H[1][k] * vk;
+            }
+            double Sm[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+            for (int l = 0; l < 5; l++) {
+                const double h0 = __shfl(hs0, l, kWave), h1 = __shfl(hs1, l, kWave);
+                Sm[0][0] += h0 * m.H[0][l];
+                Sm[0][1] += h0 * m.H[1][l];
+                Sm[1][0] += h1 * m.H[0][l];
+                Sm[1][1] += h1 * m.H[1][l];
+            }
+            Sm[0][0] += pv.p.r_meas;
+            Sm[1][1] += pv.p.r_meas;
+            double Si[2][2];
+            inv2(Sm, Si);
+            const double v0 = m.z0 - m.zh0, v1 = m.z1 - m.zh1;   // bearing NOT wrapped, :269
+            const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
+            const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
+            if (lane == 0) sh_score[i] = t0 * v0 + t1 * v1;
+        }
+        __syncthreads();
+        if (tid == 0) {                                  // :293-330
+            double best = pv.p.gate_new;
+            int idx = M;
+            for (int i = 0; i < M; i++) {
+                const double d = sh_score[i];
+                if (d < best) { best = d; idx = i; }
+            }
+            int Mn = M;
+            if (idx == M && idx < n) {                   // :318-327 new landmark
+                const double theta = st[0], x = st[1], y = st[2];
+                const double ri = sqrt(mx * mx + my * my);
+                const double phii = atan2(my, mx);
+                st[2 * idx + 3] = x + ri * cos(phii + theta);
+                st[2 * idx + 3 + 1] = y + ri * sin(phii + theta);
+                Mn = M + 1;
+                best = 0.0;
+            }
+            const int active = (best < pv.p.gate_update) && idx < n;
+            sh_M = Mn;
+            sh_lm = active ? idx : -1;
+            assoc_out[j] = sh_lm;
+            if (active) {                                // :331-381 with the FRESH pose
+                MeasTerms m;
+                measurement_terms(st[2 * idx + 3], st[2 * idx + 4], mx, my, st[0], st[1], st[2], m);
+                double S55[5][5], Sm[2][2], Si[2][2];
+                for (int k = 0; k < 5; k++)
+                    for (int l = 0; l < 5; l++) S55[k][l] = S[idx5(k, idx) * ldS + idx5(l, idx)];
+                innovation_cov(S55, m.H, pv.p.r_meas, Sm);
+                inv2(Sm, Si);
+                for (int a = 0; a < 2; a++)
+                    for (int k = 0; k < 5; k++) sh_H[a * 5 + k] = m.H[a][k];
+                sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
+                sh_nu[0] = m.z0 - m.zh0;
+                sh_nu[1] = normalize_angle(m.z1 - m.zh1);
+                touch_landmark(pv, b, idx);
+            }
+        }
+        __syncthreads();
+        const int lm = sh_lm;
+        if (lm < 0) continue;                            // dropped (uniform)
+        double k0 = 0.0, k1 = 0.0;
+        const int r = tid;
+        if (r < N) {
+            double sht0 = 0.0, sht1 = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int c = idx5(k, lm);
+                const double p = S[r * ldS + c];
+                const double g = S[c * ldS + r];
+                sht0 += p * sh_H[k];
+                sht1 += p * sh_H[5 + k];
+                g0 += sh_H[k] * g;
+                g1 += sh_H[5 + k] * g;
+            }
+            k0 = sht0 * sh_Si[0] + sht1 * sh_Si[2];
+            k1 = sht0 * sh_Si[1] + sht1 * sh_Si[3];
+            Gg[r] = g0;
+            Gg[N + r] = g1;
+        }
+        __syncthreads();
+        if (r < N) {
+            double* row = S + r * ldS;
+            for (int c = 0; c < N; c++) row[c] = row[c] - (k0 * Gg[c] + k1 * Gg[N + c]);
+            double s = st[r] + (k0 * sh_nu[0] + k1 * sh_nu[1]);
+            if (r == 0) s = normalize_angle(s);
+            st[r] = s;
+        }
+        __syncthreads();
+    }
+
+    for (int r = tid >> 6; r < N; r += kSmallThreads / 64)
+        for (int c = tid & 63; c < N; c += 64) Sg[(size_t)r * ld + c] = S[r * ldS + c];
+    for (int r = tid; r < N; r += kSmallThreads) stg[r] = st[r];
+    if (tid == 0) {
+        AssocRec a;
+        a.known_count = sh_M; a.lm = sh_lm; a.active = sh_lm >= 0; a.pad = 0; a.best = 0.0;
+        pv.assoc[b] = a;
+    }
+}
+
 size_t small_lds_bytes(int N) { return sizeof(double) * ((size_t)N * (N | 1) + 3 * (size_t)N); }
 int small_max_dim() { return kSmallThreads < 104 ? kSmallThreads : 104; }  // N <= 104: 87 KB of LDS, one lane per row
 
 hipError_t small_prepare() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_measure),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_measure),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_associate),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
+}
+
+void launch_small_associate(const PoolView& pv, const double* meas, int J, int known_count, int* assoc_out,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(k_small_associate, dim3(pv.B), dim3(kSmallThreads), small_lds_bytes(pv.N), s, pv, meas, J,
+                       known_count, assoc_out);
 }
 
 void launch_small_measure(const PoolView& pv, const double* sensor, const unsigned char* visible, int do_init,

@@ -462,3 +462,24 @@ def test_small_map_path_is_bit_identical(hip, n):
         f.close()
     assert log.corrections > 20
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("n", [3, 20, 50])
+def test_small_map_association_is_bit_identical(hip, n):
+    """data_association() as one LDS-resident launch (N <= 104) vs the maha / decide / gain / rank-2 chain."""
+    cfg = synth.SimConfig(n=n, steps=50, seed=500 + n, half_extent=1.5, min_spacing=0.1, max_visible_dis=0.9, vmax=6)
+    log = synth.make_unknown_log(cfg)
+    outs = []
+    for enable in (True, False):
+        f = hip.EKF_SLAM(n)
+        f.set_small_map_path(enable)
+        k = np.zeros(n, dtype=np.uint8)
+        dec = []
+        for t in range(50):
+            f.prediction(log.twist[t, 0])
+            dec.append(f.data_association(log.meas_xy[t, 0, :log.count[t, 0]], k).copy())
+        outs.append((f.state, f.cov, k.copy(), dec))
+        f.close()
+    assert sum(len(d) for d in outs[0][3]) > 30
+    assert np.array_equal(outs[0][2], outs[1][2]) and all(np.array_equal(a, b) for a, b in zip(outs[0][3], outs[1][3]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
