@@ -483,3 +483,16 @@ def test_small_map_association_is_bit_identical(hip, n):
     assert sum(len(d) for d in outs[0][3]) > 30
     assert np.array_equal(outs[0][2], outs[1][2]) and all(np.array_equal(a, b) for a, b in zip(outs[0][3], outs[1][3]))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_zero_landmark_filter(hip, oracle):
+    """n = 0: a pure odometry filter (N = 3) -- every entry point must still behave."""
+    f, o = hip.EKF_SLAM(0), oracle.OracleEKF(0, oracle.DENSE)
+    for dth, dx in ((0.1, 0.05), (0.0, 0.02), (-0.2, 0.01)):
+        f.prediction((dth, dx)); o.prediction(dth, dx)
+        f.measurement(np.zeros(0), np.zeros(0, dtype=np.uint8)); o.measurement(np.zeros(0), np.zeros(0, dtype=np.uint8))
+    k = np.zeros(0, dtype=np.uint8)
+    assert f.data_association(np.array([[1.0, 0.0]]), k)[0] == -1       # map full by construction: dropped
+    assert f.getStateLandmark().size == 0
+    assert np.abs(f.state - o.state).max() < 1e-14 and np.abs(f.cov - o.cov).max() < 1e-16
+    f.close()
