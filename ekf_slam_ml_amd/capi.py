@@ -32,7 +32,8 @@ SYMBOLS = [
     "ekf_maha_scores", "ekf_get_pose", "ekf_get_landmarks", "ekf_dim", "ekf_get_state", "ekf_set_state",
     "ekf_get_cov", "ekf_set_cov", "ekf_get_init_flag", "ekf_set_init_flag", "ekf_sync", "ekf_set_tuning", "ekf_set_active_prefix", "ekf_set_small_map_path", "ekf_set_active_set", "ekf_batch_set_active_set", "ekf_batch_get_touched",
     "ekf_batch_create", "ekf_batch_destroy", "ekf_batch_reset", "ekf_batch_device_bytes",
-    "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_get_state", "ekf_batch_get_cov",
+    "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_upload_unknown_log", "ekf_batch_run_unknown",
+    "ekf_batch_get_known_counts", "ekf_batch_get_decisions", "ekf_batch_set_active_prefix", "ekf_batch_get_state", "ekf_batch_get_cov",
     "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
     "ekf_set_update_mode", "ekf_batch_set_update_mode",
     "ekf_default_sim_params", "ekf_batch_simulate_known_log", "ekf_batch_download_log", "ekf_batch_mc_stats",
@@ -55,6 +56,10 @@ class Params(C.Structure):
 
 class KnownLogC(C.Structure):
     _fields_ = [("T", C.c_int), ("vmax", C.c_int), ("twist", _dp), ("lm_idx", _ip), ("z_xy", _dp), ("init_xy", _dp)]
+
+
+class UnknownLogC(C.Structure):
+    _fields_ = [("T", C.c_int), ("jmax", C.c_int), ("twist", _dp), ("count", _ip), ("meas_xy", _dp)]
 
 
 class SimParams(C.Structure):
@@ -117,6 +122,11 @@ def load():
         "ekf_set_active_set": [h, C.c_int],
         "ekf_batch_set_active_set": [h, C.c_int],
         "ekf_batch_get_touched": [h, _ip],
+        "ekf_batch_upload_unknown_log": [h, C.POINTER(UnknownLogC)],
+        "ekf_batch_run_unknown": [h, C.c_int, C.c_int, C.c_int, C.POINTER(RunStats)],
+        "ekf_batch_get_known_counts": [h, _ip],
+        "ekf_batch_get_decisions": [h, _ip],
+        "ekf_batch_set_active_prefix": [h, C.c_int],
         "ekf_set_tuning": [h, C.c_int, C.c_int, C.c_int],
         "ekf_batch_create": [C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.POINTER(h)],
         "ekf_batch_destroy": [h],
@@ -376,6 +386,38 @@ class BatchEKF:
         _check(self._lib.ekf_batch_run_known(self._h, t_begin, self.T if t_end is None else t_end,
                                              int(time_kernels), C.byref(st)))
         return st.as_dict()
+
+    def upload_unknown_log(self, twist, count, meas_xy):
+        """twist[T,B,2], count[T,B], meas_xy[T,B,jmax,2]: prediction + data_association per step."""
+        tw = np.ascontiguousarray(twist, dtype=np.float64)
+        ct = np.ascontiguousarray(count, dtype=np.int32)
+        me = np.ascontiguousarray(meas_xy, dtype=np.float64)
+        T, B = tw.shape[0], tw.shape[1]
+        if B != self.B or tw.shape != (T, B, 2) or ct.shape != (T, B) or me.ndim != 4 or me.shape[:2] != (T, B) \
+                or me.shape[3] != 2:
+            raise ValueError("log arrays must be twist[T,B,2], count[T,B], meas_xy[T,B,jmax,2]")
+        log = UnknownLogC(T, me.shape[2], _d(tw), ct.ctypes.data_as(_ip), _d(me))
+        _check(self._lib.ekf_batch_upload_unknown_log(self._h, C.byref(log)))
+        self.uT, self._jmax = T, me.shape[2]
+
+    def run_unknown(self, t_begin=0, t_end=None, time_kernels=False):
+        st = RunStats()
+        _check(self._lib.ekf_batch_run_unknown(self._h, t_begin, self.uT if t_end is None else t_end,
+                                               int(time_kernels), C.byref(st)))
+        return st.as_dict()
+
+    def set_active_prefix(self, enable=True):
+        _check(self._lib.ekf_batch_set_active_prefix(self._h, int(bool(enable))))
+
+    def known_counts(self):
+        out = np.empty(self.B, dtype=np.int32)
+        _check(self._lib.ekf_batch_get_known_counts(self._h, out.ctypes.data_as(_ip)))
+        return out
+
+    def decisions(self):
+        out = np.empty((self.uT, self.B, self._jmax), dtype=np.int32)
+        _check(self._lib.ekf_batch_get_decisions(self._h, out.ctypes.data_as(_ip)))
+        return out
 
     def state(self, b):
         out = np.empty(self.N)

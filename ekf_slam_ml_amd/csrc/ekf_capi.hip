@@ -116,6 +116,16 @@ struct Pool {
     size_t log_bytes = 0;
     std::vector<int> slot_active;  // [T][vmax]
 
+    // uploaded unknown-association log
+    int uT = 0, ujmax = 0;
+    double* ulog_twist = nullptr;  // [T][B][2]
+    int* ulog_count = nullptr;     // [T][B]
+    double* ulog_meas = nullptr;   // [T][B][jmax][2]
+    int* ulog_assoc = nullptr;     // [T][B][jmax] decisions
+    unsigned long long* corr_counter = nullptr;
+    std::vector<int> ucount_host;  // [T][B]
+    size_t ulog_bytes = 0;
+
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 
@@ -282,7 +292,7 @@ struct Pool {
         void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, pv.touch_flag, pv.touch_list,
                         pv.touch_count, scores, meas_dev,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
-                        Uf, Vf, state_alt, log_truth};
+                        Uf, Vf, state_alt, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, corr_counter};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();
@@ -573,9 +583,11 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
             if (P.touched_hwm > m) m = P.touched_hwm;
             pva.N = 3 + 2 * m;
         }
-        ekf::launch_maha(P.pv, mj, P.scores, -1, P.stream);                               // :300-309
-        ekf::launch_assoc_decide(P.pv, mj, P.scores, P.assoc_out_dev, 0, j, P.stream);    // :293-330
+        const ekf::MeasSrc ms{mj, 2, nullptr, 0};
+        ekf::launch_maha(P.pv, ms, P.scores, -1, P.stream);                                        // :300-309
+        ekf::launch_assoc_decide(P.pv, ms, P.scores, P.assoc_out_dev, 0, j, nullptr, P.stream);    // :293-330
         src.meas = mj;
+        src.meas_stride = 2;
         ekf::launch_gain(pva, src, P.stream);                                             // :331-385
         ekf::launch_rank2(pva, P.tuning, P.stream);                                       // :389-390
     }
@@ -601,7 +613,7 @@ ekf_status ekf_maha_scores(ekf_handle h, double meas_x, double meas_y, int M, do
     EKFC(P.ensure_meas_capacity(1));
     const double m[2] = {meas_x, meas_y};
     EKFC(P.upload(P.meas_dev, m, sizeof(m)));
-    ekf::launch_maha(P.pv, P.meas_dev, P.scores, M, P.stream);
+    ekf::launch_maha(P.pv, ekf::MeasSrc{P.meas_dev, 2, nullptr, 0}, P.scores, M, P.stream);
     EKFC(checked_launch());
     return P.download(scores_out, P.scores, sizeof(double) * M);
 }
@@ -678,6 +690,11 @@ ekf_status ekf_set_active_prefix(ekf_handle h, int enable) {
     h->pool.active_prefix = enable ? 1 : 0;
     return EKF_OK;
 }
+ekf_status ekf_batch_set_active_prefix(ekf_batch_handle hb, int enable) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    hb->pool.active_prefix = enable ? 1 : 0;
+    return EKF_OK;
+}
 ekf_status ekf_sync(ekf_handle h) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     return h->pool.sync();
@@ -720,7 +737,7 @@ ekf_status ekf_batch_reset(ekf_batch_handle hb) {
 
 ekf_status ekf_batch_device_bytes(ekf_batch_handle hb, size_t* bytes) {
     if (!hb || !bytes) return fail(EKF_ERR_INVALID, "null argument");
-    *bytes = hb->pool.dev_bytes + hb->pool.log_bytes;
+    *bytes = hb->pool.dev_bytes + hb->pool.log_bytes + hb->pool.ulog_bytes;
     return EKF_OK;
 }
 
@@ -898,6 +915,7 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
     if (t_begin < 0 || t_end > P.T || t_begin > t_end) return fail(EKF_ERR_INVALID, "step range outside the uploaded log");
     EKFC(P.use());
     const int B = P.pv.B, vmax = P.vmax;
+    P.touched_hwm = P.pv.n;  // a known log corrects arbitrary indices: no discovered-prefix structure afterwards
     size_t launches = 0;
     long long corrections = 0;
     for (int t = t_begin; t < t_end; t++)
@@ -980,6 +998,162 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
             delayed ? per_pass * (double)B : (launches ? per_pass * (double)corrections / (double)launches : 0.0);
     }
     return EKF_OK;
+}
+
+// ---- batched unknown data association ---------------------------------------------------------
+
+static ekf_status free_ulog(Pool& P) {
+    HIPC(hipStreamSynchronize(P.stream));
+    for (void* p : {(void*)P.ulog_twist, (void*)P.ulog_count, (void*)P.ulog_meas, (void*)P.ulog_assoc})
+        if (p) HIPC(hipFree(p));
+    P.ulog_twist = nullptr; P.ulog_count = nullptr; P.ulog_meas = nullptr; P.ulog_assoc = nullptr;
+    P.uT = 0; P.ujmax = 0; P.ulog_bytes = 0;
+    P.ucount_host.clear();
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_upload_unknown_log(ekf_batch_handle hb, const ekf_unknown_log* log) {
+    if (!hb || !log || !log->twist || !log->count || log->T <= 0 || log->jmax < 0 || (log->jmax > 0 && !log->meas_xy))
+        return fail(EKF_ERR_INVALID, "ekf_batch_upload_unknown_log: bad argument");
+    Pool& P = hb->pool;
+    EKFC(P.use());
+    const int B = P.pv.B, T = log->T, jmax = log->jmax;
+    for (size_t i = 0; i < (size_t)T * B; i++)
+        if (log->count[i] < 0 || log->count[i] > jmax)
+            return fail(EKF_ERR_INVALID, "unknown log: count must lie in 0..jmax");
+    EKFC(free_ulog(P));
+    const size_t n_tw = (size_t)T * B * 2, n_ct = (size_t)T * B, n_me = n_ct * jmax * 2, n_as = n_ct * jmax;
+    HIPC(hipMalloc((void**)&P.ulog_twist, sizeof(double) * n_tw));
+    HIPC(hipMalloc((void**)&P.ulog_count, sizeof(int) * n_ct));
+    HIPC(hipMalloc((void**)&P.ulog_meas, sizeof(double) * (n_me ? n_me : 1)));
+    HIPC(hipMalloc((void**)&P.ulog_assoc, sizeof(int) * (n_as ? n_as : 1)));
+    if (!P.corr_counter) HIPC(hipMalloc((void**)&P.corr_counter, sizeof(unsigned long long)));
+    P.ulog_bytes = sizeof(double) * (n_tw + n_me) + sizeof(int) * (n_ct + n_as);
+    HIPC(hipMemcpy(P.ulog_twist, log->twist, sizeof(double) * n_tw, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(P.ulog_count, log->count, sizeof(int) * n_ct, hipMemcpyHostToDevice));
+    if (n_me) HIPC(hipMemcpy(P.ulog_meas, log->meas_xy, sizeof(double) * n_me, hipMemcpyHostToDevice));
+    if (n_as) {
+        std::vector<int> fill(n_as, -2);
+        HIPC(hipMemcpy(P.ulog_assoc, fill.data(), sizeof(int) * n_as, hipMemcpyHostToDevice));
+    }
+    P.ucount_host.assign(log->count, log->count + n_ct);
+    P.uT = T;
+    P.ujmax = jmax;
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, int time_kernels, ekf_run_stats* stats) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    Pool& P = hb->pool;
+    if (P.uT <= 0) return fail(EKF_ERR_STATE, "ekf_batch_run_unknown: no unknown-association log uploaded");
+    if (t_begin < 0 || t_end > P.uT || t_begin > t_end) return fail(EKF_ERR_INVALID, "step range outside the uploaded log");
+    EKFC(P.use());
+    EKFC(P.flush());
+    const int B = P.pv.B, n = P.pv.n, jmax = P.ujmax;
+    // Host bound of every filter's known_count, slot by slot: landmarks are appended in discovery order
+    // (ekf_slam.cpp:318-327), one per measurement at most, so known_count_b <= (its value now) + (measurements
+    // of b so far).  Corrections are then exactly confined to the leading 3 + 2*bound block (see ekf_associate).
+    std::vector<ekf::AssocRec> recs(B);
+    EKFC(P.download(recs.data(), P.pv.assoc, sizeof(ekf::AssocRec) * B));
+    std::vector<int> kc(B);
+    for (int b = 0; b < B; b++) kc[b] = recs[b].known_count;
+    std::vector<int> slots(t_end - t_begin, 0), bound((size_t)(t_end - t_begin) * (jmax > 0 ? jmax : 1), 0);
+    size_t launches = 0;
+    for (int t = t_begin; t < t_end; t++) {
+        const int* ct = P.ucount_host.data() + (size_t)t * B;
+        int smax = 0;
+        for (int b = 0; b < B; b++) if (ct[b] > smax) smax = ct[b];
+        slots[t - t_begin] = smax;
+        launches += smax;
+        for (int j = 0; j < smax; j++) {
+            int m = 0;
+            for (int b = 0; b < B; b++) {
+                const int v = kc[b] + (ct[b] > j ? j + 1 : ct[b]);
+                if (v > m) m = v;
+            }
+            bound[(size_t)(t - t_begin) * jmax + j] = m < n ? m : n;
+        }
+        for (int b = 0; b < B; b++) { kc[b] += ct[b]; if (kc[b] > n) kc[b] = n; }
+    }
+    hipEvent_t* ev = nullptr;
+    if (time_kernels && launches) {
+        ev = P.events(2 * launches);
+        if (!ev) return fail(EKF_ERR_HIP, "hipEventCreate failed");
+    }
+    HIPC(hipMemsetAsync(P.corr_counter, 0, sizeof(unsigned long long), P.stream));
+    HIPC(hipEventRecord(P.ev_begin, P.stream));
+    ekf::CmdSrc src{};
+    src.mode = ekf::SRC_ASSOC;
+    src.assoc = P.pv.assoc;
+    src.fresh_pose = 1;
+    src.meas_stride = jmax * 2;
+    ekf::PoolView pva = P.pv;
+    size_t k = 0;
+    int kc_max = 0;
+    for (int t = t_begin; t < t_end; t++) {
+        ekf::launch_predict(P.pv, P.ulog_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream);  // prediction()
+        for (int j = 0; j < slots[t - t_begin]; j++) {  // ekf_slam.cpp:291: sequential, state-carrying
+            const ekf::MeasSrc ms{P.ulog_meas + ((size_t)t * B * jmax + j) * 2, jmax * 2, P.ulog_count + (size_t)t * B, j};
+            int m = bound[(size_t)(t - t_begin) * jmax + j];
+            if (m > kc_max) kc_max = m;
+            if (P.active_prefix) {
+                if (P.touched_hwm > m) m = P.touched_hwm;
+                pva.N = 3 + 2 * m;
+            }
+            ekf::launch_maha(P.pv, ms, P.scores, -1, P.stream);
+            ekf::launch_assoc_decide(P.pv, ms, P.scores, P.ulog_assoc + (size_t)t * B * jmax, jmax, j, P.corr_counter,
+                                     P.stream);
+            src.meas = ms.xy;
+            ekf::launch_gain(pva, src, P.stream);
+            if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
+            ekf::launch_rank2(pva, P.tuning, P.stream);
+            if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
+            k++;
+        }
+    }
+    HIPC(hipEventRecord(P.ev_end, P.stream));
+    EKFC(checked_launch());
+    unsigned long long corr = 0;
+    EKFC(P.download(&corr, P.corr_counter, sizeof(corr)));
+    if (kc_max > P.touched_hwm) P.touched_hwm = kc_max;
+    P.touched_bound = P.touched_bound + kc_max < n ? P.touched_bound + kc_max : n;
+    P.touch_bound_base = P.touched_bound;
+    if (stats) {
+        float ms = 0.f;
+        HIPC(hipEventElapsedTime(&ms, P.ev_begin, P.ev_end));
+        stats->elapsed_ms = ms;
+        stats->rank2_ms = 0.0;
+        stats->rank2_launches = (long long)k;
+        if (ev)
+            for (size_t i = 0; i < k; i++) {
+                float m = 0.f;
+                HIPC(hipEventElapsedTime(&m, ev[2 * i], ev[2 * i + 1]));
+                stats->rank2_ms += m;
+            }
+        stats->corrections = (long long)corr;
+        stats->filter_steps = (long long)B * (t_end - t_begin);
+        // a correction streams only the discovered prefix; the dense figure is the upper bound
+        stats->rank2_bytes_per_launch = 0.0;
+    }
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_get_known_counts(ekf_batch_handle hb, int* out) {
+    if (!hb || !out) return fail(EKF_ERR_INVALID, "null argument");
+    Pool& P = hb->pool;
+    EKFC(P.use());
+    std::vector<ekf::AssocRec> recs(P.pv.B);
+    EKFC(P.download(recs.data(), P.pv.assoc, sizeof(ekf::AssocRec) * P.pv.B));
+    for (int b = 0; b < P.pv.B; b++) out[b] = recs[b].known_count;
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_get_decisions(ekf_batch_handle hb, int* out) {
+    if (!hb || !out) return fail(EKF_ERR_INVALID, "null argument");
+    Pool& P = hb->pool;
+    if (P.uT <= 0) return fail(EKF_ERR_STATE, "no unknown-association log on the device");
+    EKFC(P.use());
+    return P.download(out, P.ulog_assoc, sizeof(int) * (size_t)P.uT * P.pv.B * P.ujmax);
 }
 
 ekf_status ekf_batch_get_state(ekf_batch_handle hb, int b, double* out) {

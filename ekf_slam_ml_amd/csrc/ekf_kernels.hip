@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
     } else {
         const AssocRec a = src.assoc[b];
         lm = a.active ? a.lm : -1;
-        sx = src.meas[(size_t)b * 2];
-        sy = src.meas[(size_t)b * 2 + 1];
+        sx = src.meas[(size_t)b * src.meas_stride];
+        sy = src.meas[(size_t)b * src.meas_stride + 1];
     }
     if (lm < 0 || lm >= pv.n) {  // nothing to correct for this filter in this slot
         if (blockIdx.x == 0 && tid == 0) pv.rec[b].active = 0;
@@ -505,8 +505,10 @@ __global__ void k_touch_all(PoolView pv) {
 // shuffles in the CPU restatement's summation order; the innovation bearing is NOT wrapped (:269).
 // grid (ceil(n/4), B), 4 waves per workgroup.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_maha(PoolView pv, const double* meas, double* scores, int m_override) {
+__global__ __launch_bounds__(256) void k_maha(PoolView pv, MeasSrc ms, double* scores, int m_override) {
     const int b = blockIdx.y;
+    if (ms.count && ms.j >= ms.count[b]) return;  // this filter has no measurement in this slot
+    const double* meas = ms.xy + (size_t)b * ms.stride;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int i = blockIdx.x * 4 + wave;
     const int M = m_override >= 0 ? m_override : pv.assoc[b].known_count;
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(256) void k_maha(PoolView pv, const double* meas, d
     if (lane < 25) v = Sg[(size_t)idx5(lane / 5, i) * ld + idx5(lane % 5, i)];
 
     MeasTerms m;  // fresh pose per score, :219-221
-    measurement_terms(st[2 * i + 3], st[2 * i + 4], meas[(size_t)b * 2], meas[(size_t)b * 2 + 1], st[0], st[1], st[2], m);
+    measurement_terms(st[2 * i + 3], st[2 * i + 4], meas[0], meas[1], st[0], st[1], st[2], m);
 
     // lanes l = 0..4 build column l of H*Sigma[c5,c5]
     const int l5 = lane < 5 ? lane : 4;
@@ -564,10 +566,20 @@ __global__ void k_assoc_begin(PoolView pv, const int* known_count_dev, int known
 // min-reduction; NaN scores never win (`d < min` is false).  New landmark initialisation
 // (:200-214, :318-327) and the gate_update test (:330) run on one lane.  grid (B), 256 threads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_assoc_decide(PoolView pv, const double* meas, const double* scores,
-                                                      int* assoc_out, int out_stride, int j) {
+__global__ __launch_bounds__(256) void k_assoc_decide(PoolView pv, MeasSrc ms, const double* scores,
+                                                      int* assoc_out, int out_stride, int j,
+                                                      unsigned long long* corr_counter) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    if (ms.count && ms.j >= ms.count[b]) {  // no measurement in this slot: nothing is decided, nothing corrected
+        if (tid == 0) {
+            pv.assoc[b].lm = -1;
+            pv.assoc[b].active = 0;
+            if (assoc_out) assoc_out[(size_t)b * out_stride + j] = -2;
+        }
+        return;
+    }
+    const double* meas = ms.xy + (size_t)b * ms.stride;
     __shared__ double sh_d[4];
     __shared__ int sh_i[4];
     const int M = pv.assoc[b].known_count;
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(256) void k_assoc_decide(PoolView pv, const double*
         double* st = pv.state + (size_t)b * pv.ld;
         if (idx == M && idx < pv.n) {  // :318-327 new landmark
             const double theta = st[0], x = st[1], y = st[2];
-            const double sx = meas[(size_t)b * 2], sy = meas[(size_t)b * 2 + 1];
+            const double sx = meas[0], sy = meas[1];
             const double ri = sqrt(sx * sx + sy * sy);
             const double phii = atan2(sy, sx);
             st[2 * idx + 3] = x + ri * cos(phii + theta);
@@ -612,6 +624,7 @@ __global__ __launch_bounds__(256) void k_assoc_decide(PoolView pv, const double*
         a.best = best;
         pv.assoc[b] = a;
         if (assoc_out) assoc_out[(size_t)b * out_stride + j] = a.lm;
+        if (corr_counter && active) atomicAdd(corr_counter, 1ull);
     }
 }
 
@@ -727,18 +740,19 @@ void launch_touch_all(const PoolView& pv, hipStream_t s) {
     hipLaunchKernelGGL(k_touch_all, dim3(pv.B), dim3(256), 0, s, pv);
 }
 
-void launch_maha(const PoolView& pv, const double* meas, double* scores, int m_override, hipStream_t s) {
+void launch_maha(const PoolView& pv, const MeasSrc& ms, double* scores, int m_override, hipStream_t s) {
     if (pv.n <= 0) return;
-    hipLaunchKernelGGL(k_maha, dim3((pv.n + 3) / 4, pv.B), dim3(256), 0, s, pv, meas, scores, m_override);
+    hipLaunchKernelGGL(k_maha, dim3((pv.n + 3) / 4, pv.B), dim3(256), 0, s, pv, ms, scores, m_override);
 }
 
 void launch_assoc_begin(const PoolView& pv, const int* known_count_dev, int known_count_imm, hipStream_t s) {
     hipLaunchKernelGGL(k_assoc_begin, dim3((pv.B + 255) / 256), dim3(256), 0, s, pv, known_count_dev, known_count_imm);
 }
 
-void launch_assoc_decide(const PoolView& pv, const double* meas, const double* scores, int* assoc_out,
-                         int out_stride, int j, hipStream_t s) {
-    hipLaunchKernelGGL(k_assoc_decide, dim3(pv.B), dim3(256), 0, s, pv, meas, scores, assoc_out, out_stride, j);
+void launch_assoc_decide(const PoolView& pv, const MeasSrc& ms, const double* scores, int* assoc_out,
+                         int out_stride, int j, unsigned long long* corr_counter, hipStream_t s) {
+    hipLaunchKernelGGL(k_assoc_decide, dim3(pv.B), dim3(256), 0, s, pv, ms, scores, assoc_out, out_stride, j,
+                       corr_counter);
 }
 
 void launch_checksum(const PoolView& pv, double* out, hipStream_t s) {

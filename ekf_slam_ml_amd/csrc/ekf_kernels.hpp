@@ -70,10 +70,19 @@ struct CmdSrc {
     const double* z_xy;     // SRC_COMPACT_LOG: [B][vmax][2]
     int vmax, v;
     const AssocRec* assoc;  // SRC_ASSOC: per-filter decision
-    const double* meas;     // SRC_ASSOC: [B][2] current measurement
+    const double* meas;     // SRC_ASSOC: current measurement of filter b at meas[b * meas_stride + {0,1}]
+    int meas_stride;        //            (2 for a single filter; jmax*2 inside a batch log step)
     int fresh_pose;         // 1: read (theta,x,y) from state (:331-333); 0: from snap (:109-111)
     int write_snap;         // 1: this is the first correction of a measurement() call -- its fresh pose IS
                             //    the pose captured at :109-111; record it in snap for the corrections after it
+};
+
+// The current measurement of every filter for the association kernels.
+struct MeasSrc {
+    const double* xy;   // filter b reads xy[b * stride + {0, 1}]
+    int stride;
+    const int* count;   // nullable: filter b takes part in slot j iff j < count[b]
+    int j;
 };
 
 struct PoolView {
@@ -194,12 +203,12 @@ void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s);
 void launch_rank2_active(const PoolView& pv, const Rank2Tuning& t, int max_touched, hipStream_t s);
 void launch_touch_all(const PoolView& pv, hipStream_t s);  // marks every landmark touched (after set_cov)
 // data_association(): scores for landmarks [0, known_count) of every filter, one landmark per wavefront
-void launch_maha(const PoolView& pv, const double* meas /*[B][2]*/, double* scores /*[B][n]*/, int m_override,
-                 hipStream_t s);
+void launch_maha(const PoolView& pv, const MeasSrc& ms, double* scores /*[B][n]*/, int m_override, hipStream_t s);
 void launch_assoc_begin(const PoolView& pv, const int* known_count_dev, int known_count_imm, hipStream_t s);
 // decision for measurement j of every filter; assoc_out (nullable) gets [b*out_stride + j] = landmark or -1
-void launch_assoc_decide(const PoolView& pv, const double* meas, const double* scores, int* assoc_out,
-                         int out_stride, int j, hipStream_t s);
+// corr_counter (nullable): += number of filters whose decision leads to a correction
+void launch_assoc_decide(const PoolView& pv, const MeasSrc& ms, const double* scores, int* assoc_out,
+                         int out_stride, int j, unsigned long long* corr_counter, hipStream_t s);
 // out[b][4] += {sum state, sum |state|, sum sigma, sum |sigma|}; caller zeroes out first
 void launch_checksum(const PoolView& pv, double* out, hipStream_t s);
 // batched rigid2d::CircleFitting::approxCirclePositions (ekf_circles.hip): S scans of nb beams ->

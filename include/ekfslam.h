@@ -104,6 +104,7 @@ ekf_status ekf_set_init_flag(ekf_handle h, int flag);
  * leading (3 + 2*known_count) block of the state; enable != 0 (default) streams only that block. Results are
  * bit-identical to enable == 0 for finite states. */
 ekf_status ekf_set_active_prefix(ekf_handle h, int enable);
+ekf_status ekf_batch_set_active_prefix(ekf_batch_handle hb, int enable);
 /* Active-set covariance update (opt-in, default 0; reported separately from the dense contract path):
  * the eager correction streams only the rows of the TOUCHED set -- the pose rows and the rows of landmarks
  * that have ever been corrected.  Every other row has K(r,:) = 0 exactly (its landmark still carries the
@@ -155,6 +156,33 @@ ekf_status ekf_batch_upload_known_log(ekf_batch_handle hb, const ekf_known_log* 
  * waits for completion.  time_kernels != 0 brackets every rank-2 launch with HIP events. */
 ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int time_kernels,
                                ekf_run_stats* stats);
+
+/* Unknown-association log: per step one twist and up to jmax robot-frame circle centres per filter --
+ * the node loop of nuslam/src/unknown_data_assoc.cpp:300-323 (prediction(twist), then
+ * data_association(measures, known_list)) for B independent robots. */
+typedef struct ekf_unknown_log {
+    int T;                 /* steps */
+    int jmax;              /* measurement slots per (step, filter) */
+    const double* twist;   /* [T][B][2]  (angular, linearX) */
+    const int* count;      /* [T][B]     measurements of filter b in step t, 0..jmax */
+    const double* meas_xy; /* [T][B][jmax][2] robot-frame (x, y); slots >= count are ignored */
+} ekf_unknown_log;
+ekf_status ekf_batch_upload_unknown_log(ekf_batch_handle hb, const ekf_unknown_log* log);
+/* Runs steps [t_begin, t_end) of the uploaded unknown-association log: per step prediction()
+ * (ekf_slam.cpp:55-106), then per measurement slot the Mahalanobis scores (:217-276), the
+ * gate decision / landmark initialisation (:293-330) and the correction (:331-390) of every filter
+ * that has a measurement in the slot.  Each filter's known_count (the leading run of its
+ * known_list, :281-288) lives on the device and carries over between runs until ekf_batch_reset.
+ * Always eager (pending delayed corrections are flushed first).  stats->corrections counts the
+ * corrections actually applied (decided on the device). */
+ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, int time_kernels,
+                                 ekf_run_stats* stats);
+/* known_count of every filter: out[B]. */
+ekf_status ekf_batch_get_known_counts(ekf_batch_handle hb, int* out);
+/* Decisions of the uploaded unknown log's steps run so far: out = [T][B][jmax], landmark index
+ * corrected, -1 = measurement dropped (:330), -2 = no measurement in the slot / step not run. */
+ekf_status ekf_batch_get_decisions(ekf_batch_handle hb, int* out);
+
 ekf_status ekf_batch_get_state(ekf_batch_handle hb, int b, double* out /* N */);
 ekf_status ekf_batch_get_cov(ekf_batch_handle hb, int b, double* out /* N*N row-major */);
 /* All poses at once: out = [B][3] (theta, x, y) -- the Monte-Carlo read-back. */
