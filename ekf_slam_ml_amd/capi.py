@@ -38,6 +38,7 @@ SYMBOLS = [
     "ekf_set_update_mode", "ekf_batch_set_update_mode",
     "ekf_default_sim_params", "ekf_batch_simulate_known_log", "ekf_batch_download_log", "ekf_batch_mc_stats",
     "ekf_circle_fit_scans",
+    "ekf_default_lidar_params", "ekf_batch_simulate_unknown_log", "ekf_batch_download_unknown_log", "ekf_simulate_scans",
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
 ]
 
@@ -70,6 +71,20 @@ class SimParams(C.Structure):
                 ("wheel_radius", C.c_double), ("ticks_per_step", C.c_int)]
 
 
+class LidarParams(C.Structure):
+    """ekf_lidar_params (include/ekfslam.h): the simulator's 2-D lidar."""
+    _fields_ = [("n_beams", C.c_int), ("range_std", C.c_double), ("range_max", C.c_double),
+                ("border_width", C.c_double), ("tube_radius", C.c_double)]
+
+
+def default_lidar(**kw):
+    lp = LidarParams()
+    load().ekf_default_lidar_params(C.byref(lp))
+    for k, v in kw.items():
+        setattr(lp, k, v)
+    return lp
+
+
 class RunStats(C.Structure):
     _fields_ = [("elapsed_ms", C.c_double), ("rank2_ms", C.c_double), ("rank2_launches", C.c_longlong),
                 ("corrections", C.c_longlong), ("filter_steps", C.c_longlong),
@@ -99,6 +114,8 @@ def load():
     lib.ekf_default_params.argtypes = [C.POINTER(Params)]
     lib.ekf_device_count.restype = C.c_int
     lib.ekf_default_sim_params.argtypes = [C.POINTER(SimParams)]
+    lib.ekf_default_lidar_params.argtypes = [C.POINTER(LidarParams)]
+    lib.ekf_default_lidar_params.restype = None
     sig = {
         "ekf_create": [C.c_int, C.POINTER(Params), C.c_int, C.POINTER(h)],
         "ekf_destroy": [h],
@@ -144,6 +161,10 @@ def load():
         "ekf_batch_simulate_known_log": [h, C.POINTER(SimParams), _dp, C.c_int, C.c_int],
         "ekf_batch_download_log": [h, _dp, _ip, _dp, _dp, _dp],
         "ekf_batch_mc_stats": [h, C.c_int, _dp],
+        "ekf_batch_simulate_unknown_log": [h, C.POINTER(SimParams), C.POINTER(LidarParams), _dp, C.c_int, C.c_int],
+        "ekf_batch_download_unknown_log": [h, _dp, _ip, _dp, _dp],
+        "ekf_simulate_scans": [C.c_int, C.POINTER(SimParams), C.POINTER(LidarParams), _dp, C.c_int, _dp, C.c_int,
+                               C.c_int, _dp],
         "ekf_circle_fit_scans": [C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _ip, _dp, _ip],
         "ekf_dense_create": [C.c_int, C.c_int, C.POINTER(h)],
         "ekf_dense_destroy": [h],
@@ -351,6 +372,37 @@ class BatchEKF:
         _check(self._lib.ekf_batch_upload_known_log(self._h, C.byref(log)))
         self.T, self._vmax = T, li.shape[2]
 
+    def _sim_params(self, cfg):
+        sp = SimParams()
+        self._lib.ekf_default_sim_params(C.byref(sp))
+        sp.seed, sp.first_filter_id = int(cfg.seed), int(cfg.first_filter_id)
+        sp.v_cmd, sp.w_cmd, sp.vx_std, sp.the_std = cfg.v_cmd, cfg.w_cmd, cfg.vx_std, cfg.the_std
+        sp.slip_min, sp.slip_max, sp.sensor_std, sp.max_visible_dis = cfg.slip_min, cfg.slip_max, cfg.sensor_std, cfg.max_visible_dis
+        sp.ticks_per_step = cfg.ticks_per_step
+        return sp
+
+    def simulate_unknown_log(self, cfg, world, steps=None, jmax=None, lidar=None):
+        """Unknown-association inputs generated ON THE DEVICE: the fake sensor's shuffled readings (lidar=None;
+        host twin synth.make_unknown_log) or simulated laser scans pushed through the batched circle fitting
+        (lidar = LidarParams; host twins synth.make_scans + the circle checker)."""
+        w = np.ascontiguousarray(world, dtype=np.float64)
+        if w.shape != (self.n, 2):
+            raise ValueError("world must be [n, 2]")
+        T = int(cfg.steps if steps is None else steps)
+        J = int(cfg.vmax if jmax is None else jmax)
+        sp = self._sim_params(cfg)
+        _check(self._lib.ekf_batch_simulate_unknown_log(self._h, C.byref(sp), C.byref(lidar) if lidar is not None else None,
+                                                        _d(w), T, J))
+        self.uT, self._jmax = T, J
+
+    def download_unknown_log(self, want_truth=True):
+        T, B, J = self.uT, self.B, self._jmax
+        tw, ct, me = np.empty((T, B, 2)), np.empty((T, B), dtype=np.int32), np.empty((T, B, J, 2))
+        tp = np.empty((T, B, 3)) if want_truth else None
+        _check(self._lib.ekf_batch_download_unknown_log(self._h, _d(tw), ct.ctypes.data_as(_ip), _d(me),
+                                                        _d(tp) if want_truth else None))
+        return tw, ct, me, tp
+
     def simulate_known_log(self, cfg, world, steps=None, vmax=None):
         """Generate the log ON THE DEVICE from a synth.SimConfig (same noise model and random-number
         addressing as synth.make_known_log, which stays the host-side twin for the tests)."""
@@ -500,6 +552,21 @@ class DensePropagator:
 
 
 MAX_CLUSTERS = 128
+
+
+def simulate_scans(poses, world, seed=7, first_filter_id=0, step=0, lidar=None, device=-1):
+    """poses [S, 3] = (theta, x, y) -> ranges [S, n_beams] from the on-device lidar simulator (host twin:
+    synth.make_scans with fid = first_filter_id + s and the same step)."""
+    lib = load()
+    sp = SimParams()
+    lib.ekf_default_sim_params(C.byref(sp))
+    sp.seed, sp.first_filter_id = int(seed), int(first_filter_id)
+    lp = lidar if lidar is not None else default_lidar()
+    ps = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 3)
+    w = np.ascontiguousarray(world, dtype=np.float64).reshape(-1, 2)
+    out = np.empty((len(ps), lp.n_beams))
+    _check(lib.ekf_simulate_scans(device, C.byref(sp), C.byref(lp), _d(w), len(w), _d(ps), len(ps), int(step), _d(out)))
+    return out
 
 
 def circle_fit_scans(ranges, max_out=32, device=-1, want_all=False):

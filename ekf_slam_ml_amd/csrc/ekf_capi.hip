@@ -122,6 +122,8 @@ struct Pool {
     int* ulog_count = nullptr;     // [T][B]
     double* ulog_meas = nullptr;   // [T][B][jmax][2]
     int* ulog_assoc = nullptr;     // [T][B][jmax] decisions
+    double* ulog_truth = nullptr;  // [T][B][3], simulated logs only
+    int truth_is_unknown_log = 0;  // which simulated log ekf_batch_mc_stats refers to (the latest)
     unsigned long long* corr_counter = nullptr;
     std::vector<int> ucount_host;  // [T][B]
     size_t ulog_bytes = 0;
@@ -292,7 +294,7 @@ struct Pool {
         void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, pv.touch_flag, pv.touch_list,
                         pv.touch_count, scores, meas_dev,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
-                        Uf, Vf, state_alt, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, corr_counter};
+                        Uf, Vf, state_alt, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();
@@ -814,6 +816,7 @@ ekf_status ekf_batch_simulate_known_log(ekf_batch_handle hb, const ekf_sim_param
     (void)hipFree(d_active);
     if (st != EKF_OK) return st;
     P.T = T;
+    P.truth_is_unknown_log = 0;
     P.vmax = vmax;
     return EKF_OK;
 }
@@ -838,11 +841,13 @@ ekf_status ekf_batch_download_log(ekf_batch_handle hb, double* twist, int* lm_id
 ekf_status ekf_batch_mc_stats(ekf_batch_handle hb, int t, double out[6]) {
     if (!hb || !out) return fail(EKF_ERR_INVALID, "null argument");
     Pool& P = hb->pool;
-    if (!P.log_truth) return fail(EKF_ERR_STATE, "ekf_batch_mc_stats needs a simulated log (ground truth)");
-    if (t < 0 || t >= P.T) return fail(EKF_ERR_INVALID, "step outside the log");
+    const double* truth = P.truth_is_unknown_log ? P.ulog_truth : P.log_truth;
+    const int Tl = P.truth_is_unknown_log ? P.uT : P.T;
+    if (!truth) return fail(EKF_ERR_STATE, "ekf_batch_mc_stats needs a simulated log (ground truth)");
+    if (t < 0 || t >= Tl) return fail(EKF_ERR_INVALID, "step outside the log");
     EKFC(P.use());
     EKFC(P.flush());
-    ekf::launch_mc_stats(P.pv, P.log_truth + (size_t)t * P.pv.B * 3, P.digest_dev, P.stream);
+    ekf::launch_mc_stats(P.pv, truth + (size_t)t * P.pv.B * 3, P.digest_dev, P.stream);
     EKFC(checked_launch());
     std::vector<double> h((size_t)4 * P.pv.B);
     EKFC(P.download(h.data(), P.digest_dev, sizeof(double) * h.size()));
@@ -1004,9 +1009,10 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
 
 static ekf_status free_ulog(Pool& P) {
     HIPC(hipStreamSynchronize(P.stream));
-    for (void* p : {(void*)P.ulog_twist, (void*)P.ulog_count, (void*)P.ulog_meas, (void*)P.ulog_assoc})
+    for (void* p : {(void*)P.ulog_twist, (void*)P.ulog_count, (void*)P.ulog_meas, (void*)P.ulog_assoc, (void*)P.ulog_truth})
         if (p) HIPC(hipFree(p));
-    P.ulog_twist = nullptr; P.ulog_count = nullptr; P.ulog_meas = nullptr; P.ulog_assoc = nullptr;
+    P.ulog_twist = nullptr; P.ulog_count = nullptr; P.ulog_meas = nullptr; P.ulog_assoc = nullptr; P.ulog_truth = nullptr;
+    P.truth_is_unknown_log = 0;
     P.uT = 0; P.ujmax = 0; P.ulog_bytes = 0;
     P.ucount_host.clear();
     return EKF_OK;
@@ -1040,6 +1046,140 @@ ekf_status ekf_batch_upload_unknown_log(ekf_batch_handle hb, const ekf_unknown_l
     P.uT = T;
     P.ujmax = jmax;
     return EKF_OK;
+}
+
+void ekf_default_lidar_params(ekf_lidar_params* out) {
+    if (!out) return;
+    out->n_beams = 360;          // tube_world.cpp:452
+    out->range_std = 0.005;      // noise_param.yaml
+    out->range_max = 3.5;        // tube_world.cpp:476
+    out->border_width = 2.0;     // tube_param.yaml
+    out->tube_radius = 0.0762;   // tube_param.yaml
+}
+
+static ekf::SimParams to_sim(const ekf_sim_params* sp) {
+    return ekf::SimParams{sp->seed, sp->first_filter_id, sp->v_cmd, sp->w_cmd, sp->vx_std, sp->the_std, sp->slip_min,
+                          sp->slip_max, sp->sensor_std, sp->max_visible_dis, sp->wheel_base, sp->wheel_radius,
+                          sp->ticks_per_step};
+}
+
+static bool lidar_ok(const ekf_lidar_params* lp) {
+    return lp->n_beams >= 8 && lp->n_beams <= ekf::circles_max_beams() && lp->range_max > 0 && lp->border_width > 0 &&
+           lp->tube_radius > 0 && lp->range_std >= 0;
+}
+
+ekf_status ekf_batch_simulate_unknown_log(ekf_batch_handle hb, const ekf_sim_params* sp, const ekf_lidar_params* lidar,
+                                          const double* world_xy, int T, int jmax) {
+    if (!hb || !sp || !world_xy || T <= 0 || jmax < 1 || jmax > 64 || sp->ticks_per_step < 1 || (lidar && !lidar_ok(lidar)))
+        return fail(EKF_ERR_INVALID, "ekf_batch_simulate_unknown_log: bad argument (1 <= jmax <= 64, 8 <= n_beams <= 1024)");
+    Pool& P = hb->pool;
+    EKFC(P.use());
+    EKFC(free_ulog(P));
+    const int B = P.pv.B, n = P.pv.n;
+    const size_t n_tw = (size_t)T * B * 2, n_ct = (size_t)T * B, n_me = n_ct * jmax * 2, n_as = n_ct * jmax, n_tr = n_ct * 3;
+    HIPC(hipMalloc((void**)&P.ulog_twist, sizeof(double) * n_tw));
+    HIPC(hipMalloc((void**)&P.ulog_count, sizeof(int) * n_ct));
+    HIPC(hipMalloc((void**)&P.ulog_meas, sizeof(double) * n_me));
+    HIPC(hipMalloc((void**)&P.ulog_assoc, sizeof(int) * n_as));
+    HIPC(hipMalloc((void**)&P.ulog_truth, sizeof(double) * n_tr));
+    if (!P.corr_counter) HIPC(hipMalloc((void**)&P.corr_counter, sizeof(unsigned long long)));
+    P.ulog_bytes = sizeof(double) * (n_tw + n_me + n_tr) + sizeof(int) * (n_ct + n_as);
+    double *d_world = nullptr, *d_ranges = nullptr, *d_radii = nullptr;
+    auto body = [&]() -> ekf_status {
+        HIPC(hipMalloc((void**)&d_world, sizeof(double) * 2 * (n > 0 ? n : 1)));
+        if (n > 0) HIPC(hipMemcpyAsync(d_world, world_xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, P.stream));
+        HIPC(hipMemsetAsync(P.ulog_meas, 0, sizeof(double) * n_me, P.stream));
+        HIPC(hipMemsetAsync(P.ulog_assoc, 0xFF, sizeof(int) * n_as, P.stream));  // -1; run_unknown overwrites
+        const ekf::SimParams p = to_sim(sp);
+        if (!lidar) {
+            ekf::launch_sim_unknown(p, B, n, T, jmax, d_world, P.ulog_twist, P.ulog_truth, P.ulog_count, P.ulog_meas,
+                                    true, P.stream);
+        } else {
+            ekf::launch_sim_unknown(p, B, n, T, jmax, d_world, P.ulog_twist, P.ulog_truth, nullptr, nullptr, true, P.stream);
+            const ekf::LidarParams lp{lidar->n_beams, lidar->range_std, lidar->range_max, lidar->border_width,
+                                      lidar->tube_radius};
+            // scans are produced and consumed in chunks of whole steps (<= 256 MiB of ranges at a time)
+            size_t steps_per_chunk = ((size_t)256 << 20) / (sizeof(double) * lp.n_beams * B);
+            if (steps_per_chunk < 1) steps_per_chunk = 1;
+            if (steps_per_chunk > (size_t)T) steps_per_chunk = T;
+            HIPC(hipMalloc((void**)&d_ranges, sizeof(double) * steps_per_chunk * B * lp.n_beams));
+            HIPC(hipMalloc((void**)&d_radii, sizeof(double) * steps_per_chunk * B * jmax));
+            for (int t0 = 0; t0 < T; t0 += (int)steps_per_chunk) {
+                const int tc = T - t0 < (int)steps_per_chunk ? T - t0 : (int)steps_per_chunk;
+                const int S = tc * B;
+                ekf::launch_sim_scans(p, lp, B, n, S, t0, d_world, P.ulog_truth + (size_t)t0 * B * 3, d_ranges, P.stream);
+                ekf::launch_circles(d_ranges, S, lp.n_beams, jmax, P.ulog_meas + (size_t)t0 * B * jmax * 2, d_radii,
+                                    P.ulog_count + (size_t)t0 * B, nullptr, nullptr, P.stream);
+            }
+        }
+        HIPC(hipGetLastError());
+        P.ucount_host.assign(n_ct, 0);
+        HIPC(hipMemcpyAsync(P.ucount_host.data(), P.ulog_count, sizeof(int) * n_ct, hipMemcpyDeviceToHost, P.stream));
+        HIPC(hipStreamSynchronize(P.stream));
+        return EKF_OK;
+    };
+    const ekf_status st = body();
+    for (void* q : {(void*)d_world, (void*)d_ranges, (void*)d_radii})
+        if (q) (void)hipFree(q);
+    if (st != EKF_OK) return st;
+    // decisions start as "not run" (-2)
+    {
+        std::vector<int> fill(n_as, -2);
+        HIPC(hipMemcpy(P.ulog_assoc, fill.data(), sizeof(int) * n_as, hipMemcpyHostToDevice));
+    }
+    P.uT = T;
+    P.ujmax = jmax;
+    P.truth_is_unknown_log = 1;
+    return EKF_OK;
+}
+
+ekf_status ekf_batch_download_unknown_log(ekf_batch_handle hb, double* twist, int* count, double* meas_xy,
+                                          double* true_pose) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    Pool& P = hb->pool;
+    if (P.uT <= 0) return fail(EKF_ERR_STATE, "no unknown-association log on the device");
+    if (true_pose && !P.ulog_truth) return fail(EKF_ERR_STATE, "the uploaded log carries no simulated truth");
+    EKFC(P.use());
+    HIPC(hipStreamSynchronize(P.stream));
+    const size_t B = P.pv.B, T = P.uT, J = P.ujmax;
+    if (twist) HIPC(hipMemcpy(twist, P.ulog_twist, sizeof(double) * T * B * 2, hipMemcpyDeviceToHost));
+    if (count) HIPC(hipMemcpy(count, P.ulog_count, sizeof(int) * T * B, hipMemcpyDeviceToHost));
+    if (meas_xy && J) HIPC(hipMemcpy(meas_xy, P.ulog_meas, sizeof(double) * T * B * J * 2, hipMemcpyDeviceToHost));
+    if (true_pose) HIPC(hipMemcpy(true_pose, P.ulog_truth, sizeof(double) * T * B * 3, hipMemcpyDeviceToHost));
+    return EKF_OK;
+}
+
+ekf_status ekf_simulate_scans(int device, const ekf_sim_params* sp, const ekf_lidar_params* lidar, const double* world_xy,
+                              int n, const double* poses, int S, int step, double* ranges_out) {
+    if (!sp || !lidar || !lidar_ok(lidar) || n < 0 || (n > 0 && !world_xy) || S < 0 || (S > 0 && (!poses || !ranges_out)) ||
+        step < 0)
+        return fail(EKF_ERR_INVALID, "ekf_simulate_scans: bad argument (8 <= n_beams <= 1024)");
+    if (S == 0) return EKF_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(EKF_ERR_NO_DEVICE, "no HIP device visible: libekfslam_hip has no CPU path");
+    if (device < 0) HIPC(hipGetDevice(&device));
+    if (device >= count) return fail(EKF_ERR_INVALID, "device index out of range");
+    HIPC(hipSetDevice(device));
+    double *d_world = nullptr, *d_poses = nullptr, *d_ranges = nullptr;
+    auto body = [&]() -> ekf_status {
+        HIPC(hipMalloc((void**)&d_world, sizeof(double) * 2 * (n > 0 ? n : 1)));
+        HIPC(hipMalloc((void**)&d_poses, sizeof(double) * 3 * S));
+        HIPC(hipMalloc((void**)&d_ranges, sizeof(double) * (size_t)S * lidar->n_beams));
+        if (n > 0) HIPC(hipMemcpy(d_world, world_xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_poses, poses, sizeof(double) * 3 * S, hipMemcpyHostToDevice));
+        const ekf::LidarParams lp{lidar->n_beams, lidar->range_std, lidar->range_max, lidar->border_width,
+                                  lidar->tube_radius};
+        // B = S, t0 = step: scan s draws the noise stream of filter first_filter_id + s at that step
+        ekf::launch_sim_scans(to_sim(sp), lp, S, n, S, step, d_world, d_poses, d_ranges, nullptr);
+        HIPC(hipGetLastError());
+        HIPC(hipMemcpy(ranges_out, d_ranges, sizeof(double) * (size_t)S * lidar->n_beams, hipMemcpyDeviceToHost));
+        return EKF_OK;
+    };
+    const ekf_status st = body();
+    for (void* q : {(void*)d_world, (void*)d_poses, (void*)d_ranges})
+        if (q) (void)hipFree(q);
+    return st;
 }
 
 ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, int time_kernels, ekf_run_stats* stats) {
@@ -1098,7 +1238,8 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
             if (m > kc_max) kc_max = m;
             if (P.active_prefix) {
                 if (P.touched_hwm > m) m = P.touched_hwm;
-                pva.N = 3 + 2 * m;
+                pva.N = 3 + 2 * m;  // launch bound over the pool; every filter narrows it to its own prefix
+                src.min_active = 3 + 2 * P.touched_hwm;
             }
             ekf::launch_maha(P.pv, ms, P.scores, -1, P.stream);
             ekf::launch_assoc_decide(P.pv, ms, P.scores, P.ulog_assoc + (size_t)t * B * jmax, jmax, j, P.corr_counter,
@@ -1115,6 +1256,10 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     EKFC(checked_launch());
     unsigned long long corr = 0;
     EKFC(P.download(&corr, P.corr_counter, sizeof(corr)));
+    EKFC(P.download(recs.data(), P.pv.assoc, sizeof(ekf::AssocRec) * B));
+    kc_max = 0;  // the real high-water mark replaces the slot-by-slot bound
+    for (int b = 0; b < B; b++) if (recs[b].known_count > kc_max) kc_max = recs[b].known_count;
+    if (kc_max > n) kc_max = n;
     if (kc_max > P.touched_hwm) P.touched_hwm = kc_max;
     P.touched_bound = P.touched_bound + kc_max < n ? P.touched_bound + kc_max : n;
     P.touch_bound_base = P.touched_bound;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
         sh_nu[1] = normalize_angle(m.z1 - m.zh1);  // :183
         if (blockIdx.x == 0) {
             CorrRec rcd;
-            rcd.nu0 = sh_nu[0]; rcd.nu1 = sh_nu[1]; rcd.active = 1; rcd.lm = lm;
+            rcd.nu0 = sh_nu[0]; rcd.nu1 = sh_nu[1]; rcd.active = 1; rcd.lm = lm; rcd.n_active = 0; rcd.pad = 0;
             pv.rec[b] = rcd;
             touch_landmark(pv, b, lm);
         }

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_init(PoolView pv) {
         if (threadIdx.x < 4) pv.snap[(size_t)b * 4 + threadIdx.x] = 0.0;
         for (int i = threadIdx.x; i < pv.n; i += 256) pv.touch_flag[(size_t)b * pv.n + i] = 0;
         if (threadIdx.x == 0) {
-            pv.rec[b] = CorrRec{0.0, 0.0, 0, -1};
+            pv.rec[b] = CorrRec{0.0, 0.0, 0, -1, 0, 0};
             pv.assoc[b] = AssocRec{0, -1, 0, 0, 0.0};
             pv.touch_count[b] = 0;
         }
@@ -205,12 +205,14 @@ __global__ __launch_bounds__(256) void k_measure_begin(PoolView pv, const double
 __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
-    const int N = pv.N, ld = pv.ld;
+    int N = pv.N;
+    const int ld = pv.ld;
     __shared__ double sh_S55[25];
     __shared__ double sh_H[10];
     __shared__ double sh_Si[4];
 
     int lm = -1;
+    int n_active = 0;
     double sx = 0.0, sy = 0.0;
     if (src.mode == SRC_SENSOR_VECTOR) {
         lm = src.lm_imm;
@@ -226,6 +228,10 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
     } else {
         const AssocRec a = src.assoc[b];
         lm = a.active ? a.lm : -1;
+        if (src.min_active > 0) {  // this filter's own discovered prefix
+            n_active = max(src.min_active, 3 + 2 * a.known_count);
+            if (n_active < N) N = n_active; else n_active = 0;
+        }
         sx = src.meas[(size_t)b * src.meas_stride];
         sy = src.meas[(size_t)b * src.meas_stride + 1];
     }
@@ -233,6 +239,8 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
         if (blockIdx.x == 0 && tid == 0) pv.rec[b].active = 0;
         return;
     }
+    // K and G beyond this filter's active dimension are never read by its rank-2 pass
+    if (n_active > 0 && blockIdx.x > 0 && blockIdx.x * 256 >= N) return;
 
     const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
     const double* st = pv.state + (size_t)b * ld;
@@ -287,6 +295,8 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
             rc.nu1 = normalize_angle(m.z1 - m.zh1);   // :183
             rc.active = 1;
             rc.lm = lm;
+            rc.n_active = n_active;
+            rc.pad = 0;
             pv.rec[b] = rc;
             touch_landmark(pv, b, lm);
         }
@@ -344,19 +354,22 @@ __device__ __forceinline__ void st2(double2_t* p, double2_t v) {
 template <int U, bool NT>
 __global__ __launch_bounds__(256) void k_rank2(double* __restrict__ sigma, const double* __restrict__ Kg_all,
                                                const double* __restrict__ Gh_all, const CorrRec* __restrict__ rec,
-                                               double* __restrict__ state, int N, int ld, size_t sigma_stride,
-                                               int rows_per_block) {
+                                               double* __restrict__ state, int N_launch, int ld,
+                                               size_t sigma_stride, int rows_per_block) {
     // N is the ACTIVE dimension: rows and columns >= N are exactly untouched by this correction (their K
     // and G entries are exact zeros), which data_association() exploits -- landmarks are appended in
     // discovery order, so everything beyond 3 + 2*known_count still holds its constructor value.
     const int b = blockIdx.z;
     if (!rec[b].active) return;
+    const int na = rec[b].n_active;  // per-filter discovered prefix (batched data association), 0 = none
+    const int N = na > 0 ? min(na, N_launch) : N_launch;
     const int ld2n = ld >> 1;
     const int ld2a = (N + 1) >> 1;  // double2 columns that hold an active column
     const int c2 = blockIdx.x * 256 + threadIdx.x;
     const double2_t* __restrict__ Kg = reinterpret_cast<const double2_t*>(Kg_all + (size_t)b * 2 * ld);
     const int row_begin = blockIdx.y * rows_per_block;
     const int row_end = min(N, row_begin + rows_per_block);
+    if (row_begin >= N) return;
 
     if (c2 < ld2a) {
         const double2_t g0 = reinterpret_cast<const double2_t*>(Gh_all + (size_t)b * 2 * ld)[c2];

@@ -49,6 +49,8 @@ struct CorrRec {
     double nu0, nu1;  // innovation, bearing wrapped (ekf_slam.cpp:182-183)
     int active;       // 0 -> the rank-2 kernel skips this filter
     int lm;           // landmark index being corrected
+    int n_active;     // > 0: this filter's own active dimension (<= the launch's N); 0: the launch's N
+    int pad;
 };
 
 // Per-filter association state (data_association(), ekf_slam.cpp:278-402).
@@ -72,6 +74,8 @@ struct CmdSrc {
     const AssocRec* assoc;  // SRC_ASSOC: per-filter decision
     const double* meas;     // SRC_ASSOC: current measurement of filter b at meas[b * meas_stride + {0,1}]
     int meas_stride;        //            (2 for a single filter; jmax*2 inside a batch log step)
+    int min_active;         // SRC_ASSOC, > 0: per-filter discovered prefix -- filter b is corrected within its
+                            // leading max(min_active, 3 + 2*known_count_b) block only (exact, see ekf_associate)
     int fresh_pose;         // 1: read (theta,x,y) from state (:331-333); 0: from snap (:109-111)
     int write_snap;         // 1: this is the first correction of a measurement() call -- its fresh pose IS
                             //    the pose captured at :109-111; record it in snap for the corrections after it

@@ -38,7 +38,7 @@ __device__ __forceinline__ double normal01(unsigned long long seed, unsigned lon
     u1 = fmax(u1, 1.1102230246251565e-16);  // 2^-53
     return sqrt(-2.0 * log(u1)) * cos(2.0 * 3.141592653589793 * u2);
 }
-constexpr unsigned long long KIND_CMD = 1, KIND_SLIP = 2, KIND_SENSOR = 3;
+constexpr unsigned long long KIND_CMD = 1, KIND_SLIP = 2, KIND_SENSOR = 3, KIND_SHUFFLE = 5, KIND_SCAN = 6;
 
 // DiffDrive::getBodyTwistForUpdate, rigid2d/src/diff_drive.cpp:38-47
 __device__ __forceinline__ void body_twist(const SimParams& p, double left, double right, double& ang, double& lin) {
@@ -174,6 +174,154 @@ __global__ __launch_bounds__(256) void k_sim_readings(SimParams p, int B, int n,
     }
 }
 
+// The kmax nearest landmarks within the visibility radius of pose (c, s, px, py), by repeated lexicographic
+// (d2, index) minimum over the workgroup: chosen[0..n_chosen) in ascending distance.  256 threads.
+__device__ void select_nearest(int n, int kmax, double lim2, const double* __restrict__ world, double c, double s,
+                               double px, double py, int* chosen, int* n_chosen, int* exhausted, double* sh_d,
+                               int* sh_i) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { *n_chosen = 0; *exhausted = 0; }
+    __syncthreads();
+    for (int pass = 0; pass < kmax; pass++) {
+        double best = 1.0e300;
+        int bi = 0x7fffffff;
+        const int nch = *n_chosen;
+        for (int i = tid; i < n; i += 256) {
+            bool taken = false;
+            for (int q = 0; q < nch; q++) taken |= (chosen[q] == i);
+            if (taken) continue;
+            const double dx = world[2 * i] - px, dy = world[2 * i + 1] - py;
+            const double rx = c * dx + s * dy, ry = -s * dx + c * dy;
+            const double d2 = rx * rx + ry * ry;
+            if (d2 < best || (d2 == best && i < bi)) { best = d2; bi = i; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_down(best, off, kWave);
+            const int oi = __shfl_down(bi, off, kWave);
+            if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+        }
+        if ((tid & 63) == 0) { sh_d[tid >> 6] = best; sh_i[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; w++)
+                if (sh_d[w] < best || (sh_d[w] == best && sh_i[w] < bi)) { best = sh_d[w]; bi = sh_i[w]; }
+            if (bi != 0x7fffffff && best <= lim2) chosen[(*n_chosen)++] = bi;
+            else *exhausted = 1;  // nothing left within the radius
+        }
+        __syncthreads();
+        if (*exhausted) break;  // uniform
+    }
+}
+
+// One workgroup per (filter, step): the scan_measures vector of nuslam/src/unknown_data_assoc.cpp:309-320 as the
+// fake sensor would fill it -- noisy robot-frame (x, y) of the (at most jmax nearest) landmarks within the
+// visibility radius, in a per-step shuffled order (ascending KIND_SHUFFLE key), EVERY step including step 0.
+// Host twin: synth.make_unknown_log.
+__global__ __launch_bounds__(256) void k_sim_unknown_readings(SimParams p, int B, int n, int jmax,
+                                                              const double* __restrict__ world,
+                                                              const double* __restrict__ truth,
+                                                              int* __restrict__ count, double* __restrict__ meas) {
+    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const unsigned long long fid = (unsigned long long)p.first_filter_id + b;
+    const double th = truth[((size_t)t * B + b) * 3], px = truth[((size_t)t * B + b) * 3 + 1],
+                 py = truth[((size_t)t * B + b) * 3 + 2];
+    const double c = cos(th), s = sin(th);
+    __shared__ double sh_d[4];
+    __shared__ int sh_i[4];
+    __shared__ int chosen[64];
+    __shared__ double key[64];
+    __shared__ int n_chosen, exhausted;
+    select_nearest(n, jmax < 64 ? jmax : 64, p.max_visible_dis * p.max_visible_dis, world, c, s, px, py, chosen,
+                   &n_chosen, &exhausted, sh_d, sh_i);
+    if (tid == 0) {
+        const int m = n_chosen;
+        for (int a = 0; a < m; a++) key[a] = uniform01(p.seed, fid, t, KIND_SHUFFLE, (unsigned long long)chosen[a]);
+        for (int a = 1; a < m; a++) {  // ascending (key, landmark)
+            const int v = chosen[a];
+            const double kv = key[a];
+            int q = a - 1;
+            while (q >= 0 && (key[q] > kv || (key[q] == kv && chosen[q] > v))) {
+                chosen[q + 1] = chosen[q]; key[q + 1] = key[q]; q--;
+            }
+            chosen[q + 1] = v; key[q + 1] = kv;
+        }
+        double* zz = meas + ((size_t)t * B + b) * jmax * 2;
+        for (int v = 0; v < jmax; v++) {
+            if (v < m) {
+                const int i = chosen[v];
+                const double dx = world[2 * i] - px, dy = world[2 * i + 1] - py;
+                zz[2 * v] = (c * dx + s * dy) + p.sensor_std * normal01(p.seed, fid, t, KIND_SENSOR, 2ull * i);
+                zz[2 * v + 1] = (-s * dx + c * dy) + p.sensor_std * normal01(p.seed, fid, t, KIND_SENSOR, 2ull * i + 1);
+            } else {
+                zz[2 * v] = 0.0; zz[2 * v + 1] = 0.0;
+            }
+        }
+        count[(size_t)t * B + b] = m;
+    }
+}
+
+// One workgroup per scan: n_beams ranges of a 2-D lidar at poses[s] in a square walled world with n tubes of
+// one radius (publishScan, nurtlesim/src/tube_world.cpp:451-577, as clean ray geometry: nearest of the wall hit,
+// range_max and the first intersection with every tube), plus N(0, range_std) per beam (:571).
+// Host twin: synth.make_scans.  Candidate tubes (centre within range_max + radius) are compacted into LDS first.
+constexpr int kCandMax = 512;
+__global__ __launch_bounds__(256) void k_sim_scans(SimParams p, LidarParams lp, int B, int n, int t0,
+                                                   const double* __restrict__ world,
+                                                   const double* __restrict__ poses, double* __restrict__ ranges) {
+    const int sidx = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long fid = (unsigned long long)p.first_filter_id + (unsigned long long)(sidx % B);
+    const unsigned long long step = (unsigned long long)(t0 + sidx / B);
+    const double th0 = poses[(size_t)sidx * 3], ox = poses[(size_t)sidx * 3 + 1], oy = poses[(size_t)sidx * 3 + 2];
+    __shared__ double cand[2 * kCandMax];
+    __shared__ int n_cand;
+    if (tid == 0) n_cand = 0;
+    __syncthreads();
+    const double reach = lp.range_max + lp.tube_radius;
+    for (int i = tid; i < n; i += 256) {
+        const double fx = ox - world[2 * i], fy = oy - world[2 * i + 1];
+        if (fx * fx + fy * fy <= reach * reach) {
+            const int k = atomicAdd(&n_cand, 1);
+            if (k < kCandMax) { cand[2 * k] = fx; cand[2 * k + 1] = fy; }
+        }
+    }
+    __syncthreads();
+    const int nc = n_cand;
+    const double half = lp.border_width / 2.0, r2 = lp.tube_radius * lp.tube_radius;
+    for (int i = tid; i < lp.n_beams; i += 256) {
+        const double ang = 2.0 * 3.141592653589793 * (double)i / (double)lp.n_beams;
+        const double th = th0 + ang;
+        const double dx = cos(th), dy = sin(th);
+        const double inf = __builtin_huge_val();
+        const double tx = dx > 0 ? (half - ox) / dx : (dx < 0 ? (-half - ox) / dx : inf);
+        const double ty = dy > 0 ? (half - oy) / dy : (dy < 0 ? (-half - oy) / dy : inf);
+        double r = fmin(fmin(tx, ty), lp.range_max);
+        if (nc <= kCandMax) {
+            for (int k = 0; k < nc; k++) {
+                const double fx = cand[2 * k], fy = cand[2 * k + 1];
+                const double bq = fx * dx + fy * dy;
+                const double cq = fx * fx + fy * fy - r2;
+                const double disc = bq * bq - cq;
+                if (disc > 0) {
+                    const double tt = -bq - sqrt(disc);
+                    if (tt > 0 && tt < r) r = tt;
+                }
+            }
+        } else {  // more tubes in reach than the LDS list holds: walk the whole map
+            for (int k = 0; k < n; k++) {
+                const double fx = ox - world[2 * k], fy = oy - world[2 * k + 1];
+                const double bq = fx * dx + fy * dy;
+                const double cq = fx * fx + fy * fy - r2;
+                const double disc = bq * bq - cq;
+                if (disc > 0) {
+                    const double tt = -bq - sqrt(disc);
+                    if (tt > 0 && tt < r) r = tt;
+                }
+            }
+        }
+        ranges[(size_t)sidx * lp.n_beams + i] = r + lp.range_std * normal01(p.seed, fid, step, KIND_SCAN, (unsigned long long)i);
+    }
+}
+
 // Monte-Carlo consistency of the batch against the simulated truth of step t: per filter the pose error
 // e = (wrap(theta - theta*), x - x*, y - y*), NEES = e^T P^-1 e with P = Sigma[0:3,0:3].
 // out[b][4] = {NEES, ex^2 + ey^2, etheta^2, trace P}
@@ -203,6 +351,19 @@ void launch_sim(const SimParams& p, int B, int n, int T, int vmax, const double*
     hipLaunchKernelGGL(k_sim_trajectory, dim3((B + 127) / 128), dim3(128), 0, s, p, B, T, twist, truth);
     hipLaunchKernelGGL(k_sim_readings, dim3(B, T), dim3(256), 0, s, p, B, n, vmax, world, truth, lm_idx, z_xy, init_xy,
                        slot_active);
+}
+
+void launch_sim_unknown(const SimParams& p, int B, int n, int T, int jmax, const double* world, double* twist,
+                        double* truth, int* count, double* meas, bool trajectory, hipStream_t s) {
+    if (trajectory) hipLaunchKernelGGL(k_sim_trajectory, dim3((B + 127) / 128), dim3(128), 0, s, p, B, T, twist, truth);
+    if (count)
+        hipLaunchKernelGGL(k_sim_unknown_readings, dim3(B, T), dim3(256), 0, s, p, B, n, jmax, world, truth, count, meas);
+}
+
+void launch_sim_scans(const SimParams& p, const LidarParams& lp, int B, int n, int S, int t0, const double* world,
+                      const double* poses, double* ranges, hipStream_t s) {
+    if (S <= 0) return;
+    hipLaunchKernelGGL(k_sim_scans, dim3(S), dim3(256), 0, s, p, lp, B, n, t0, world, poses, ranges);
 }
 
 void launch_mc_stats(const PoolView& pv, const double* truth_t, double* out, hipStream_t s) {

@@ -344,8 +344,9 @@ KIND_SCAN = 6
 
 
 def make_scans(poses, world=None, n_beams=360, seed=7, range_std=0.005, range_max=3.5,
-               border=WORLD_BORDER_WIDTH, tube_radius=TUBE_RADIUS):
-    """poses [S, 3] = (theta, x, y) -> ranges [S, n_beams] (float64), deterministic in (seed, scan id, beam)."""
+               border=WORLD_BORDER_WIDTH, tube_radius=TUBE_RADIUS, fid=None, step=0):
+    """poses [S, 3] = (theta, x, y) -> ranges [S, n_beams] (float64), deterministic in (seed, fid, step, beam);
+    fid defaults to the scan id.  Device twin: k_sim_scans (ekf_sim.hip)."""
     poses = np.asarray(poses, dtype=np.float64).reshape(-1, 3)
     if world is None:
         world = np.stack([TUBE_X, TUBE_Y], axis=1)
@@ -367,6 +368,7 @@ def make_scans(poses, world=None, n_beams=360, seed=7, range_std=0.005, range_ma
         hit = disc > 0
         t = -bq - np.sqrt(np.where(hit, disc, 0.0))
         r = np.where(hit & (t > 0) & (t < r), t, r)
-    sid = np.arange(S, dtype=np.uint64)[:, None]
-    noise = range_std * normal01(seed, sid, 0, KIND_SCAN, np.arange(n_beams, dtype=np.uint64)[None, :])
+    sid = (np.arange(S, dtype=np.uint64) if fid is None else np.asarray(fid, dtype=np.uint64).reshape(S))[:, None]
+    stp = np.broadcast_to(np.asarray(step, dtype=np.uint64).reshape(-1, 1), (S, 1))
+    noise = range_std * normal01(seed, sid, stp, KIND_SCAN, np.arange(n_beams, dtype=np.uint64)[None, :])
     return r + noise

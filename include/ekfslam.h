@@ -222,6 +222,36 @@ ekf_status ekf_batch_simulate_known_log(ekf_batch_handle hb, const ekf_sim_param
  * true_pose [T][B][3] = simulated ground truth (theta, x, y) AFTER step t (simulated logs only). */
 ekf_status ekf_batch_download_log(ekf_batch_handle hb, double* twist, int* lm_idx, double* z_xy, double* init_xy,
                                   double* true_pose);
+
+/* 2-D lidar of the simulator (publishScan, nurtlesim/src/tube_world.cpp:451-577). */
+typedef struct ekf_lidar_params {
+    int n_beams;          /* 360, tube_world.cpp:452                                      */
+    double range_std;     /* nurtlesim/config/noise_param.yaml: range_std 0.005           */
+    double range_max;     /* 3.5, tube_world.cpp:476                                      */
+    double border_width;  /* tube_param.yaml: world_border_width 2.0 (square wall)        */
+    double tube_radius;   /* tube_param.yaml: tube_radius 0.0762                          */
+} ekf_lidar_params;
+void ekf_default_lidar_params(ekf_lidar_params* out);
+/* Unknown-association inputs generated ON THE DEVICE for every filter of the batch (replaces any
+ * uploaded unknown log): the simulated trajectory / odometry twists of ekf_batch_simulate_known_log, and
+ * per (step, filter) up to jmax (<= 64) robot-frame measurements from
+ *   lidar == NULL : the fake sensor -- noisy positions of the landmarks within max_visible_dis, shuffled
+ *                   (the scan_measures vector of nuslam/src/unknown_data_assoc.cpp:309-320);
+ *   lidar != NULL : a simulated laser scan per (step, filter) pushed through the batched circle
+ *                   fitting (nuslam/src/landmarks.cpp:141 -> rigid2d::CircleFitting), scans never
+ *                   leaving the device. */
+ekf_status ekf_batch_simulate_unknown_log(ekf_batch_handle hb, const ekf_sim_params* sp,
+                                          const ekf_lidar_params* lidar, const double* world_xy, int T, int jmax);
+/* Copies the device-resident unknown log back (any pointer may be NULL): shapes as in ekf_unknown_log,
+ * true_pose [T][B][3] for simulated logs. */
+ekf_status ekf_batch_download_unknown_log(ekf_batch_handle hb, double* twist, int* count, double* meas_xy,
+                                          double* true_pose);
+/* Stand-alone scan simulator: scan s is taken from poses[s] = (theta, x, y) with the noise stream of
+ * filter sp->first_filter_id + s at step `step`; ranges_out = [S][n_beams]. */
+ekf_status ekf_simulate_scans(int device, const ekf_sim_params* sp, const ekf_lidar_params* lidar,
+                              const double* world_xy, int n, const double* poses, int S, int step,
+                              double* ranges_out);
+
 /* Consistency of the batch against the simulated truth of step t:
  * out = {mean NEES (3 dof), max NEES, RMSE position, RMSE heading, mean trace of the pose covariance,
  *        fraction of filters with NEES < 7.815 (95 % chi-square bound, 3 dof)}. */
