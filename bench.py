@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--delayed-k", type=int, default=32,
                     help="also time the delayed rank-2k update with this many corrections per flush (0 = skip)")
     ap.add_argument("--no-active-set", action="store_true", help="skip the active-set leg")
+    ap.add_argument("--no-unknown", action="store_true", help="skip the batched unknown-association leg")
     ap.add_argument("--host-log", action="store_true",
                     help="generate the synthetic log on the host (numpy) and upload it, instead of on the device")
     ap.add_argument("--rows", type=int, default=0)
@@ -199,6 +200,7 @@ def main():
                               "to the dense stream"}
         bt.set_active_set(False)
 
+    out = None
     if rank == 0:
         r2_avg_s = st["rank2_ms"] / max(st["rank2_launches"], 1) * 1e-3
         achieved = st["rank2_bytes_per_launch"] / r2_avg_s / 1e9
@@ -255,6 +257,38 @@ def main():
                                      log.init_xy[:Bc])
             gpu_state = np.stack([bt.state(b) for b in range(Bc)])  # (state after the last leg that ran)
             out["cpu_baseline"] = cpu_baseline(sub, K, 1 + W, cores, gpu_state)
+
+    # Last, separately reported leg: data_association() (a4/a5) over the same pool -- every robot discovers its map
+    # from shuffled, unlabelled readings generated on the device; scores, gate decisions, landmark initialisation
+    # and corrections all stay on the device.  Corrections are exactly confined to each filter's discovered prefix.
+    if not a.no_unknown and not a.host_log:
+        J, Tu = 8, 1 + W + K
+        ucfg = synth.config3(steps=Tu)
+        ucfg.filters, ucfg.first_filter_id, ucfg.n = B, cfg.first_filter_id, n
+        uworld = synth.make_world(n, ucfg.half_extent, ucfg.min_spacing, ucfg.seed)
+        bt.reset()
+        bt.simulate_unknown_log(ucfg, uworld, jmax=J)
+        bt.run_unknown(0, 1 + W)
+        fence()
+        t0 = time.perf_counter()
+        su = bt.run_unknown(1 + W, Tu, time_kernels=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fence()
+        uwall, ucorr, usteps = shard.reduce_throughput(t1 - t0, float(su["corrections"]), float(su["filter_steps"]),
+                                                       device=red_dev)
+        if rank == 0:
+            kc = bt.known_counts()
+            out["unknown_association"] = {
+                "value": usteps / uwall, "unit": "filter steps/s (1 step = prediction + data_association of <= 8 readings)",
+                "corrections_per_s": ucorr / uwall, "measurement_slots": su["rank2_launches"],
+                "known_landmarks_min": int(kc.min()), "known_landmarks_max": int(kc.max()),
+                "rank2_share_of_time": su["rank2_ms"] / su["elapsed_ms"],
+                "mc_consistency": bt.mc_stats(Tu - 1),
+                "note": "configs[2]'s world and sensor for every filter of the pool; landmarks are appended in discovery "
+                        "order, so each filter's corrections stream only its leading 3 + 2*known block (bit-identical "
+                        "to the full-width update, tests/test_gpu_batch_unknown.py)"}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     bt.close()
     if dist is not None:
