@@ -586,7 +586,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
             pva.N = 3 + 2 * m;
         }
         const ekf::MeasSrc ms{mj, 2, nullptr, 0};
-        ekf::launch_maha(P.pv, ms, P.scores, -1, P.stream);                                        // :300-309
+        ekf::launch_maha(P.pv, ms, P.scores, -1, known_count + j < n ? known_count + j : n, P.stream);  // :300-309
         ekf::launch_assoc_decide(P.pv, ms, P.scores, P.assoc_out_dev, 0, j, nullptr, P.stream);    // :293-330
         src.meas = mj;
         src.meas_stride = 2;
@@ -615,7 +615,7 @@ ekf_status ekf_maha_scores(ekf_handle h, double meas_x, double meas_y, int M, do
     EKFC(P.ensure_meas_capacity(1));
     const double m[2] = {meas_x, meas_y};
     EKFC(P.upload(P.meas_dev, m, sizeof(m)));
-    ekf::launch_maha(P.pv, ekf::MeasSrc{P.meas_dev, 2, nullptr, 0}, P.scores, M, P.stream);
+    ekf::launch_maha(P.pv, ekf::MeasSrc{P.meas_dev, 2, nullptr, 0}, P.scores, M, -1, P.stream);
     EKFC(checked_launch());
     return P.download(scores_out, P.scores, sizeof(double) * M);
 }
@@ -1190,30 +1190,12 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     EKFC(P.use());
     EKFC(P.flush());
     const int B = P.pv.B, n = P.pv.n, jmax = P.ujmax;
-    // Host bound of every filter's known_count, slot by slot: landmarks are appended in discovery order
-    // (ekf_slam.cpp:318-327), one per measurement at most, so known_count_b <= (its value now) + (measurements
-    // of b so far).  Corrections are then exactly confined to the leading 3 + 2*bound block (see ekf_associate).
-    std::vector<ekf::AssocRec> recs(B);
-    EKFC(P.download(recs.data(), P.pv.assoc, sizeof(ekf::AssocRec) * B));
-    std::vector<int> kc(B);
-    for (int b = 0; b < B; b++) kc[b] = recs[b].known_count;
-    std::vector<int> slots(t_end - t_begin, 0), bound((size_t)(t_end - t_begin) * (jmax > 0 ? jmax : 1), 0);
     size_t launches = 0;
     for (int t = t_begin; t < t_end; t++) {
         const int* ct = P.ucount_host.data() + (size_t)t * B;
         int smax = 0;
         for (int b = 0; b < B; b++) if (ct[b] > smax) smax = ct[b];
-        slots[t - t_begin] = smax;
         launches += smax;
-        for (int j = 0; j < smax; j++) {
-            int m = 0;
-            for (int b = 0; b < B; b++) {
-                const int v = kc[b] + (ct[b] > j ? j + 1 : ct[b]);
-                if (v > m) m = v;
-            }
-            bound[(size_t)(t - t_begin) * jmax + j] = m < n ? m : n;
-        }
-        for (int b = 0; b < B; b++) { kc[b] += ct[b]; if (kc[b] > n) kc[b] = n; }
     }
     hipEvent_t* ev = nullptr;
     if (time_kernels && launches) {
@@ -1228,20 +1210,43 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     src.fresh_pose = 1;
     src.meas_stride = jmax * 2;
     ekf::PoolView pva = P.pv;
+    // Host bound of every filter's known_count, slot by slot: landmarks are appended in discovery order
+    // (ekf_slam.cpp:318-327), one per measurement at most, so known_count_b <= (its last known value) +
+    // (measurements of b since).  It sizes the launches; each filter narrows its own correction to its real
+    // prefix on the device (CorrRec.n_active).  The bound loosens by up to jmax per step, so the real counts are
+    // read back now and then: every step for a big pool (a step is milliseconds of device work there), rarely
+    // for a small one (where the read-back's stream sync would dominate).
+    const int refresh_every = B >= 64 ? 1 : 16;
+    std::vector<ekf::AssocRec> recs(B);
+    std::vector<int> kc(B, 0);
     size_t k = 0;
     int kc_max = 0;
     for (int t = t_begin; t < t_end; t++) {
+        if ((t - t_begin) % refresh_every == 0) {
+            EKFC(P.download(recs.data(), P.pv.assoc, sizeof(ekf::AssocRec) * B));
+            for (int b = 0; b < B; b++) kc[b] = recs[b].known_count;
+        }
+        const int* ct = P.ucount_host.data() + (size_t)t * B;
+        int smax = 0;
+        for (int b = 0; b < B; b++) if (ct[b] > smax) smax = ct[b];
         ekf::launch_predict(P.pv, P.ulog_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream);  // prediction()
-        for (int j = 0; j < slots[t - t_begin]; j++) {  // ekf_slam.cpp:291: sequential, state-carrying
-            const ekf::MeasSrc ms{P.ulog_meas + ((size_t)t * B * jmax + j) * 2, jmax * 2, P.ulog_count + (size_t)t * B, j};
-            int m = bound[(size_t)(t - t_begin) * jmax + j];
+        for (int j = 0; j < smax; j++) {  // ekf_slam.cpp:291: sequential, state-carrying
+            int m_before = 0, m = 0;      // bounds of known_count before / after this slot's decision
+            for (int b = 0; b < B; b++) {
+                const int vb = kc[b] + (ct[b] > j ? j : ct[b]), va = kc[b] + (ct[b] > j ? j + 1 : ct[b]);
+                if (vb > m_before) m_before = vb;
+                if (va > m) m = va;
+            }
+            if (m > n) m = n;
+            if (m_before > n) m_before = n;
             if (m > kc_max) kc_max = m;
+            const ekf::MeasSrc ms{P.ulog_meas + ((size_t)t * B * jmax + j) * 2, jmax * 2, P.ulog_count + (size_t)t * B, j};
             if (P.active_prefix) {
                 if (P.touched_hwm > m) m = P.touched_hwm;
                 pva.N = 3 + 2 * m;  // launch bound over the pool; every filter narrows it to its own prefix
                 src.min_active = 3 + 2 * P.touched_hwm;
             }
-            ekf::launch_maha(P.pv, ms, P.scores, -1, P.stream);
+            ekf::launch_maha(P.pv, ms, P.scores, -1, m_before, P.stream);
             ekf::launch_assoc_decide(P.pv, ms, P.scores, P.ulog_assoc + (size_t)t * B * jmax, jmax, j, P.corr_counter,
                                      P.stream);
             src.meas = ms.xy;
@@ -1251,6 +1256,7 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
             if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
             k++;
         }
+        for (int b = 0; b < B; b++) { kc[b] += ct[b]; if (kc[b] > n) kc[b] = n; }
     }
     HIPC(hipEventRecord(P.ev_end, P.stream));
     EKFC(checked_launch());

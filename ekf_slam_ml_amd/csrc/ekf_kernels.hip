@@ -699,7 +699,9 @@ void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init
 }
 
 void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s) {
-    hipLaunchKernelGGL(k_gain, dim3((pv.ld + 255) / 256, pv.B), dim3(256), 0, s, pv, src);
+    // rows [0, N] only: K and G beyond the active dimension (pv.N may be a discovered prefix) are never read
+    const int cover = pv.N + 1 < pv.ld ? pv.N + 1 : pv.ld;
+    hipLaunchKernelGGL(k_gain, dim3((cover + 255) / 256, pv.B), dim3(256), 0, s, pv, src);
 }
 
 template <int U>
@@ -753,9 +755,13 @@ void launch_touch_all(const PoolView& pv, hipStream_t s) {
     hipLaunchKernelGGL(k_touch_all, dim3(pv.B), dim3(256), 0, s, pv);
 }
 
-void launch_maha(const PoolView& pv, const MeasSrc& ms, double* scores, int m_override, hipStream_t s) {
+void launch_maha(const PoolView& pv, const MeasSrc& ms, double* scores, int m_override, int m_bound,
+                 hipStream_t s) {
     if (pv.n <= 0) return;
-    hipLaunchKernelGGL(k_maha, dim3((pv.n + 3) / 4, pv.B), dim3(256), 0, s, pv, ms, scores, m_override);
+    int m = m_override >= 0 ? m_override : pv.n;  // landmarks that can be scored in this launch
+    if (m_bound >= 0 && m_bound < m) m = m_bound;
+    if (m <= 0) return;
+    hipLaunchKernelGGL(k_maha, dim3((m + 3) / 4, pv.B), dim3(256), 0, s, pv, ms, scores, m_override);
 }
 
 void launch_assoc_begin(const PoolView& pv, const int* known_count_dev, int known_count_imm, hipStream_t s) {

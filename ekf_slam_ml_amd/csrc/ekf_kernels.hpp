@@ -207,7 +207,9 @@ void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s);
 void launch_rank2_active(const PoolView& pv, const Rank2Tuning& t, int max_touched, hipStream_t s);
 void launch_touch_all(const PoolView& pv, hipStream_t s);  // marks every landmark touched (after set_cov)
 // data_association(): scores for landmarks [0, known_count) of every filter, one landmark per wavefront
-void launch_maha(const PoolView& pv, const MeasSrc& ms, double* scores /*[B][n]*/, int m_override, hipStream_t s);
+// m_bound >= 0: host-side upper bound of every filter's known_count (sizes the grid)
+void launch_maha(const PoolView& pv, const MeasSrc& ms, double* scores /*[B][n]*/, int m_override, int m_bound,
+                 hipStream_t s);
 void launch_assoc_begin(const PoolView& pv, const int* known_count_dev, int known_count_imm, hipStream_t s);
 // decision for measurement j of every filter; assoc_out (nullable) gets [b*out_stride + j] = landmark or -1
 // corr_counter (nullable): += number of filters whose decision leads to a correction
