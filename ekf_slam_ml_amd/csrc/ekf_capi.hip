@@ -147,6 +147,29 @@ struct Pool {
     int touch_bound_base = 0;                 // touched_bound when that log arrived (filters may not be fresh)
     unsigned char* visible_dev = nullptr;  // [n] (single filter)
 
+    // fused single-launch correction (single filter): the second covariance / state buffer it writes into
+    int fused = 1;
+    double* sigma_alt = nullptr;
+    double* state_fz = nullptr;
+    bool alt_synced = false;  // sigma_alt equals sigma outside the region the next fused correction rewrites
+
+    bool fused_ok() const { return fused && pv.B == 1 && pend_cap == 0 && !active_set; }
+    ekf_status ensure_alt() {
+        if (!sigma_alt) {
+            EKFC(dalloc(&sigma_alt, (size_t)pv.B * pv.sigma_stride));
+            EKFC(dalloc(&state_fz, (size_t)pv.B * pv.ld));
+            alt_synced = false;
+        }
+        if (!alt_synced) {
+            // Both buffers must agree wherever a (prefix-confined) correction does not write.  Anything that
+            // rewrites Sigma in place outside this path clears alt_synced; prediction() needs no copy -- beyond
+            // the discovered prefix it maps zeros to zeros, inside it the next fused correction rewrites all.
+            HIPC(hipMemcpyAsync(sigma_alt, pv.sigma, sizeof(double) * pv.B * pv.sigma_stride, hipMemcpyDeviceToDevice, stream));
+            alt_synced = true;
+        }
+        return EKF_OK;
+    }
+
     ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count, pend_symmetric}; }
 
     ekf_status set_update_mode(int max_pending_corrections, int symmetric_gather) {
@@ -172,6 +195,7 @@ struct Pool {
     // fold every pending correction into Sigma_base (no-op in eager mode)
     ekf_status flush() {
         if (pend_count > 0) {
+            alt_synced = false;
             ekf::launch_flush(pv, pending(), tuning, stream);
             HIPC(hipGetLastError());
             pend_count = 0;
@@ -179,19 +203,30 @@ struct Pool {
         return EKF_OK;
     }
 
-    // one landmark correction, eager (gain + covariance stream) or delayed (gain only, factors appended)
-    ekf_status correct(const ekf::CmdSrc& src) {
+    // one landmark correction, eager (gain + covariance stream) or delayed (gain only, factors appended).
+    // active_N > 0: the correction is exactly confined to the leading active_N block (data_association()).
+    ekf_status correct(const ekf::CmdSrc& src, int active_N = 0) {
         if (pend_cap > 0 && src.mode != ekf::SRC_ASSOC) {
             if (pend_count + 2 > pend_cap) EKFC(flush());
             ekf::launch_gain_delayed(pv, src, pending(), state_alt, stream);
             std::swap(pv.state, state_alt);
             pend_count += 2;
-        } else {
-            EKFC(flush());
-            ekf::launch_gain(pv, src, stream);
-            if (active_set) ekf::launch_rank2_active(pv, tuning, touched_bound, stream);
-            else ekf::launch_rank2(pv, tuning, stream);
+            return EKF_OK;
         }
+        EKFC(flush());
+        ekf::PoolView view = pv;
+        if (active_N > 0 && active_N < pv.N) view.N = active_N;
+        if (fused_ok()) {  // single filter: gain + state + covariance in one launch, out of place
+            EKFC(ensure_alt());
+            ekf::launch_correct_fused(view, src, sigma_alt, state_fz, stream);
+            std::swap(pv.sigma, sigma_alt);
+            std::swap(pv.state, state_fz);
+            return EKF_OK;
+        }
+        alt_synced = false;
+        ekf::launch_gain(view, src, stream);
+        if (active_set && active_N == 0) ekf::launch_rank2_active(pv, tuning, touched_bound, stream);
+        else ekf::launch_rank2(view, tuning, stream);
         return EKF_OK;
     }
 
@@ -285,6 +320,7 @@ struct Pool {
         ekf::launch_init(pv, stream);
         HIPC(hipGetLastError());
         init_flag = 0;
+        alt_synced = false;
         return EKF_OK;
     }
 
@@ -294,7 +330,7 @@ struct Pool {
         void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, pv.touch_flag, pv.touch_list,
                         pv.touch_count, scores, meas_dev,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
-                        Uf, Vf, state_alt, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter};
+                        Uf, Vf, state_alt, sigma_alt, state_fz, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();
@@ -366,6 +402,7 @@ struct Pool {
         if (!in || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "set_cov: bad argument");
         EKFC(use());
         EKFC(flush());
+        alt_synced = false;
         touched_hwm = pv.n;  // caller-supplied covariance: no structure may be assumed any more
         touched_bound = pv.n;
         std::fill(host_touched.begin(), host_touched.end(), 1);
@@ -492,6 +529,7 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
     HIPC(hipMemcpyAsync(c.pv.touch_list, a.pv.touch_list, sizeof(int) * (size_t)(a.pv.n > 0 ? a.pv.n : 1), hipMemcpyDeviceToDevice, c.stream));
     HIPC(hipMemcpyAsync(c.pv.touch_count, a.pv.touch_count, sizeof(int), hipMemcpyDeviceToDevice, c.stream));
     c.active_prefix = a.active_prefix;
+    c.fused = a.fused;
     return c.sync();
 }
 
@@ -511,6 +549,7 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     EKFC(P.upload2(P.sensor_dev, sensor_xy, sizeof(double) * 2 * n, visible, (size_t)n));
     if (P.small_path && P.pend_cap == 0 && P.pv.N <= ekf::small_max_dim() && n > 0) {
         // small map (the reference runs n = 20): the whole call in one LDS-resident launch
+        P.alt_synced = false;
         ekf::launch_small_measure(P.pv, P.sensor_dev, P.visible_dev, !P.init_flag, P.stream);
         P.init_flag = 1;
         for (int i = n - 1; i >= 0; i--)
@@ -557,6 +596,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     EKFC(P.upload(P.meas_dev, meas_xy, sizeof(double) * 2 * J));
     if (P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && n <= 128) {
         // small map: scores, decisions and corrections of all J measurements in one LDS-resident launch
+        P.alt_synced = false;
         ekf::launch_small_associate(P.pv, P.meas_dev, J, known_count, P.assoc_out_dev, P.stream);
         EKFC(checked_launch());
         ekf::AssocRec rec_s;
@@ -577,21 +617,20 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     // and may have holes) -- still hold their constructor values, and every correction of this call is
     // exactly confined to that leading block: K and H*Sigma are exact zeros outside it.  (Non-finite
     // states void this; they are already garbage in the reference.)
-    ekf::PoolView pva = P.pv;
     for (int j = 0; j < J; j++) {  // ekf_slam.cpp:291: sequential, state-carrying
         const double* mj = P.meas_dev + 2 * (size_t)j;
+        int active_N = 0;
         if (P.active_prefix) {
             int m = known_count + j + 1 < n ? known_count + j + 1 : n;
             if (P.touched_hwm > m) m = P.touched_hwm;
-            pva.N = 3 + 2 * m;
+            active_N = 3 + 2 * m;
         }
         const ekf::MeasSrc ms{mj, 2, nullptr, 0};
         ekf::launch_maha(P.pv, ms, P.scores, -1, known_count + j < n ? known_count + j : n, P.stream);  // :300-309
         ekf::launch_assoc_decide(P.pv, ms, P.scores, P.assoc_out_dev, 0, j, nullptr, P.stream);    // :293-330
         src.meas = mj;
         src.meas_stride = 2;
-        ekf::launch_gain(pva, src, P.stream);                                             // :331-385
-        ekf::launch_rank2(pva, P.tuning, P.stream);                                       // :389-390
+        EKFC(P.correct(src, active_N));                                                   // :331-390
     }
     EKFC(checked_launch());
     ekf::AssocRec rec;
@@ -690,6 +729,12 @@ ekf_status ekf_set_small_map_path(ekf_handle h, int enable) {
 ekf_status ekf_set_active_prefix(ekf_handle h, int enable) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     h->pool.active_prefix = enable ? 1 : 0;
+    return EKF_OK;
+}
+ekf_status ekf_set_fused_correction(ekf_handle h, int enable) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    h->pool.fused = enable ? 1 : 0;
+    h->pool.alt_synced = false;
     return EKF_OK;
 }
 ekf_status ekf_batch_set_active_prefix(ekf_batch_handle hb, int enable) {
@@ -921,6 +966,7 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
     EKFC(P.use());
     const int B = P.pv.B, vmax = P.vmax;
     P.touched_hwm = P.pv.n;  // a known log corrects arbitrary indices: no discovered-prefix structure afterwards
+    P.alt_synced = false;
     size_t launches = 0;
     long long corrections = 0;
     for (int t = t_begin; t < t_end; t++)
@@ -1189,6 +1235,7 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     if (t_begin < 0 || t_end > P.uT || t_begin > t_end) return fail(EKF_ERR_INVALID, "step range outside the uploaded log");
     EKFC(P.use());
     EKFC(P.flush());
+    P.alt_synced = false;
     const int B = P.pv.B, n = P.pv.n, jmax = P.ujmax;
     size_t launches = 0;
     for (int t = t_begin; t < t_end; t++) {

@@ -207,6 +207,9 @@ void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s);
 void launch_rank2_active(const PoolView& pv, const Rank2Tuning& t, int max_touched, hipStream_t s);
 void launch_touch_all(const PoolView& pv, hipStream_t s);  // marks every landmark touched (after set_cov)
 // data_association(): scores for landmarks [0, known_count) of every filter, one landmark per wavefront
+// gain + state + covariance of one correction in one launch, OUT OF PLACE into (sigma_next, state_next)
+// (ekf_fused.hip); the caller swaps the buffers afterwards
+void launch_correct_fused(const PoolView& pv, const CmdSrc& src, double* sigma_next, double* state_next, hipStream_t s);
 // m_bound >= 0: host-side upper bound of every filter's known_count (sizes the grid)
 void launch_maha(const PoolView& pv, const MeasSrc& ms, double* scores /*[B][n]*/, int m_override, int m_bound,
                  hipStream_t s);

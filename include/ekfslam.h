@@ -105,6 +105,11 @@ ekf_status ekf_set_init_flag(ekf_handle h, int flag);
  * bit-identical to enable == 0 for finite states. */
 ekf_status ekf_set_active_prefix(ekf_handle h, int enable);
 ekf_status ekf_batch_set_active_prefix(ekf_batch_handle hb, int enable);
+/* Single filter, maps beyond the small-map path: every eager correction (gain K, state, covariance) runs as
+ * ONE launch that writes Sigma - K(H Sigma) out of place into a second buffer; the two buffers swap after
+ * each correction (enable != 0, default).  enable == 0: the two-launch form (gain, then the in-place rank-2
+ * stream) that the batch pools use.  Bit-identical; costs a second N x N buffer. */
+ekf_status ekf_set_fused_correction(ekf_handle h, int enable);
 /* Active-set covariance update (opt-in, default 0; reported separately from the dense contract path):
  * the eager correction streams only the rows of the TOUCHED set -- the pose rows and the rows of landmarks
  * that have ever been corrected.  Every other row has K(r,:) = 0 exactly (its landmark still carries the
