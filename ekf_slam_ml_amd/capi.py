@@ -33,7 +33,7 @@ SYMBOLS = [
     "ekf_get_cov", "ekf_set_cov", "ekf_get_init_flag", "ekf_set_init_flag", "ekf_sync", "ekf_set_tuning", "ekf_set_active_prefix", "ekf_set_small_map_path", "ekf_set_active_set", "ekf_batch_set_active_set", "ekf_batch_get_touched",
     "ekf_batch_create", "ekf_batch_destroy", "ekf_batch_reset", "ekf_batch_device_bytes",
     "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_upload_unknown_log", "ekf_batch_run_unknown",
-    "ekf_batch_get_known_counts", "ekf_batch_get_decisions", "ekf_batch_set_active_prefix", "ekf_set_fused_correction", "ekf_batch_get_state", "ekf_batch_get_cov",
+    "ekf_batch_get_known_counts", "ekf_batch_get_decisions", "ekf_batch_set_active_prefix", "ekf_batch_set_small_map_path", "ekf_set_fused_correction", "ekf_batch_get_state", "ekf_batch_get_cov",
     "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
     "ekf_set_update_mode", "ekf_batch_set_update_mode",
     "ekf_default_sim_params", "ekf_batch_simulate_known_log", "ekf_batch_download_log", "ekf_batch_mc_stats",
@@ -144,6 +144,7 @@ def load():
         "ekf_batch_get_known_counts": [h, _ip],
         "ekf_batch_get_decisions": [h, _ip],
         "ekf_batch_set_active_prefix": [h, C.c_int],
+        "ekf_batch_set_small_map_path": [h, C.c_int],
         "ekf_set_fused_correction": [h, C.c_int],
         "ekf_set_tuning": [h, C.c_int, C.c_int, C.c_int],
         "ekf_batch_create": [C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.POINTER(h)],
@@ -464,6 +465,9 @@ class BatchEKF:
 
     def set_active_prefix(self, enable=True):
         _check(self._lib.ekf_batch_set_active_prefix(self._h, int(bool(enable))))
+
+    def set_small_map_path(self, enable=True):
+        _check(self._lib.ekf_batch_set_small_map_path(self._h, int(bool(enable))))
 
     def known_counts(self):
         out = np.empty(self.B, dtype=np.int32)

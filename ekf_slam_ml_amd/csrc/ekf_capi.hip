@@ -537,7 +537,11 @@ ekf_status ekf_predict(ekf_handle h, double dtheta, double dx) {
     if (!h) return fail(EKF_ERR_INVALID, "ekf_predict: null handle");
     Pool& P = h->pool;
     EKFC(P.use());
-    ekf::launch_predict(P.pv, nullptr, dtheta, dx, P.pending(), P.stream);
+    // Rows/columns of landmarks this object never corrected are exactly zero against the pose block
+    // (constructor values), and At*0*At^T + 0 = 0: the propagation is confined to the touched prefix.
+    ekf::PoolView view = P.pv;
+    if (P.active_prefix && P.pend_cap == 0 && P.touched_hwm < P.pv.n) view.N = 3 + 2 * P.touched_hwm;
+    ekf::launch_predict(view, nullptr, dtheta, dx, P.pending(), P.stream);
     return checked_launch();
 }
 
@@ -737,6 +741,11 @@ ekf_status ekf_set_fused_correction(ekf_handle h, int enable) {
     h->pool.alt_synced = false;
     return EKF_OK;
 }
+ekf_status ekf_batch_set_small_map_path(ekf_batch_handle hb, int enable) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    hb->pool.small_path = enable ? 1 : 0;
+    return EKF_OK;
+}
 ekf_status ekf_batch_set_active_prefix(ekf_batch_handle hb, int enable) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
     hb->pool.active_prefix = enable ? 1 : 0;
@@ -761,6 +770,7 @@ ekf_status ekf_batch_create(int B, int n, const ekf_params* params, int device, 
     ekf_batch_s* f = new (std::nothrow) ekf_batch_s();
     if (!f) return fail(EKF_ERR_NOMEM, "host allocation failed");
     ekf_status st = f->pool.create(B, n, params, device);
+    if (st == EKF_OK && ekf::small_prepare() != hipSuccess) st = fail(EKF_ERR_HIP, "hipFuncSetAttribute failed");
     if (st != EKF_OK) {
         f->pool.destroy();
         delete f;
@@ -1268,15 +1278,52 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     std::vector<int> kc(B, 0);
     size_t k = 0;
     int kc_max = 0;
+    // Small discovered prefixes: while every filter's 3 + 2*(known_count + readings of the step) fits the
+    // LDS-resident path, ONE launch per step does all scoring, gating, initialisation and corrections of the step
+    // for the whole pool (k_pool_associate) instead of four launches per measurement slot.
+    const bool want_small = P.small_path && P.active_prefix && n > 0;
     for (int t = t_begin; t < t_end; t++) {
-        if ((t - t_begin) % refresh_every == 0) {
+        bool fresh = false;
+        auto refresh = [&]() -> ekf_status {
             EKFC(P.download(recs.data(), P.pv.assoc, sizeof(ekf::AssocRec) * B));
             for (int b = 0; b < B; b++) kc[b] = recs[b].known_count;
-        }
+            fresh = true;
+            return EKF_OK;
+        };
+        if ((t - t_begin) % refresh_every == 0) EKFC(refresh());
         const int* ct = P.ucount_host.data() + (size_t)t * B;
         int smax = 0;
         for (int b = 0; b < B; b++) if (ct[b] > smax) smax = ct[b];
-        ekf::launch_predict(P.pv, P.ulog_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream);  // prediction()
+        auto step_dim = [&]() {  // bound of every filter's active dimension after this step
+            int m = P.touched_hwm;
+            for (int b = 0; b < B; b++) if (kc[b] + ct[b] > m) m = kc[b] + ct[b];
+            if (m > n) m = n;
+            return 3 + 2 * m;
+        };
+        int Nstep = step_dim();
+        if (want_small && smax > 0 && Nstep > ekf::small_max_dim() && !fresh) {  // is it only the bound that is loose?
+            EKFC(refresh());
+            Nstep = step_dim();
+        }
+        {   // prediction(), confined to the discovered prefix of the pool (exact: zeros map to zeros)
+            ekf::PoolView pvp = P.pv;
+            if (P.active_prefix) {
+                int m = P.touched_hwm;
+                for (int b = 0; b < B; b++) if (kc[b] > m) m = kc[b];
+                if (m < n) pvp.N = 3 + 2 * m;
+            }
+            ekf::launch_predict(pvp, P.ulog_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream);
+        }
+        if (want_small && smax > 0 && Nstep <= ekf::small_max_dim()) {
+            pva.N = Nstep;
+            if ((Nstep - 3) / 2 > kc_max) kc_max = (Nstep - 3) / 2;
+            if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
+            ekf::launch_pool_associate(pva, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
+                                       3 + 2 * P.touched_hwm, P.ulog_assoc + (size_t)t * B * jmax, P.corr_counter, P.stream);
+            if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
+            k++;
+            smax = 0;  // the step is done
+        }
         for (int j = 0; j < smax; j++) {  // ekf_slam.cpp:291: sequential, state-carrying
             int m_before = 0, m = 0;      // bounds of known_count before / after this slot's decision
             for (int b = 0; b < B; b++) {

@@ -425,12 +425,21 @@ __global__ __launch_bounds__(256) void k_rank2(double* __restrict__ sigma, const
             }
             r += rem * U;
         }
-        for (; r < row_end; r++) {  // < U leftover rows of the last row block
-            const double2_t k = Kg[r];
-            double2_t v = ld2<NT>(col + (size_t)r * ld2n);
-            v.x = v.x - (k.x * g0.x + k.y * g1.x);
-            v.y = v.y - (k.x * g0.y + k.y * g1.y);
-            st2<NT>(col + (size_t)r * ld2n, v);
+        if (r < row_end) {  // < U leftover rows of the last row block: all their loads fly together
+            const int rem = row_end - r;  // uniform
+            double2_t T[U];
+#pragma unroll
+            for (int u = 0; u < U - 1; u++)
+                if (u < rem) T[u] = ld2<NT>(col + (size_t)(r + u) * ld2n);
+#pragma unroll
+            for (int u = 0; u < U - 1; u++)
+                if (u < rem) {
+                    const double2_t k = Kg[r + u];
+                    double2_t v = T[u];
+                    v.x = v.x - (k.x * g0.x + k.y * g1.x);
+                    v.y = v.y - (k.x * g0.y + k.y * g1.y);
+                    st2<NT>(col + (size_t)(r + u) * ld2n, v);
+                }
         }
     }
 
@@ -719,7 +728,8 @@ static void launch_rank2_u(const PoolView& pv, int rows, bool nt, hipStream_t s)
 void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s) {
     // Non-temporal only when the pool cannot stay resident in the 256 MiB Infinity Cache between
     // two corrections; a single filter's covariance (32 MB at n = 1000) should stay cached.
-    const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
+    // (the bytes this launch touches: pv.N may be a discovered prefix of a much larger pool)
+    const size_t pool_bytes = (size_t)pv.B * pv.N * ((size_t)pv.N * sizeof(double));
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
     int u = t.group_rows;
     int rows = t.rows_per_block;
@@ -727,7 +737,7 @@ void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s) {
         // Measured on MI355X (profiles/): a big pool streams fastest with 32 rows per workgroup taken as
         // two 16-row groups (32 x 16 B in flight per lane, 2 waves/SIMD): 6.17 TB/s algorithmic.  A small
         // pool needs enough workgroups to cover 256 CUs a few times over.
-        const long long strips = (long long)pv.B * ((pv.ld / 2 + 255) / 256);
+        const long long strips = (long long)pv.B * (((pv.N + 1) / 2 + 255) / 256);
         const long long total = strips * pv.N;
         rows = total >= 256LL * 8 * 32 ? 32 : (total >= 256LL * 4 * 8 ? 8 : 4);
     }

@@ -232,6 +232,10 @@ void launch_small_measure(const PoolView& pv, const double* sensor, const unsign
 // whole data_association() call of a small map (single filter: pv.B == 1) in one launch
 void launch_small_associate(const PoolView& pv, const double* meas, int J, int known_count, int* assoc_out,
                             hipStream_t s);
+// one step of an unknown-association log for a pool whose every discovered prefix fits the small path:
+// pv.N = the pool-wide bound of 3 + 2*(known_count + count) (<= small_max_dim()); meas [B][jmax][2], count [B]
+void launch_pool_associate(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
+                           int* assoc_out /*[B][jmax]*/, unsigned long long* corr_counter, hipStream_t s);
 int small_max_dim();          // largest N = 3 + 2n the small path accepts
 hipError_t small_prepare();   // raises the kernel's dynamic-LDS limit (87 KB > 64 KB default)
 int max_pending();  // capacity limit of the delayed-update factor store (rows of U / V per filter)

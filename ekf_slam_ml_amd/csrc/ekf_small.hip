@@ -109,26 +109,27 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_measure(PoolView pv, co
 // new-landmark initialisation (k_assoc_decide), and the correction with the fresh pose (k_gain + k_rank2).
 // Same arithmetic as the multi-kernel chain -> bit-identical results and decisions.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSmallThreads) void k_small_associate(PoolView pv, const double* __restrict__ meas, int J,
-                                                                   int known_count_in, int* __restrict__ assoc_out) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// N: the filter's active dimension (the leading N x N block of Sigma is all these J measurements can touch);
+// returns (on every lane) the number of corrections applied.
+__device__ int small_associate_body(const PoolView& pv, int b, int N, const double* __restrict__ meas, int J,
+                                    int known_count_in, int* __restrict__ assoc_out, double* sm) {
+    const int tid = threadIdx.x;
     const int wave = tid / kWave, lane = tid % kWave;
-    const int N = pv.N, ld = pv.ld, n = pv.n;
+    const int ld = pv.ld, n = pv.n;
     const int ldS = N | 1;
     double* S = sm;
     double* st = S + (size_t)N * ldS;
     double* Gg = st + N;
     __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
     __shared__ double sh_score[128];
-    __shared__ int sh_M, sh_lm;
+    __shared__ int sh_M, sh_lm, sh_applied;
 
     double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
     double* stg = pv.state + (size_t)b * ld;
     for (int r = tid >> 6; r < N; r += kSmallThreads / 64)
         for (int c = tid & 63; c < N; c += 64) S[r * ldS + c] = Sg[(size_t)r * ld + c];
     for (int r = tid; r < N; r += kSmallThreads) st[r] = stg[r];
-    if (tid == 0) sh_M = known_count_in;
+    if (tid == 0) { sh_M = known_count_in; sh_applied = 0; }
     __syncthreads();
 
     for (int j = 0; j < J; j++) {                       // :291 sequential, state-carrying
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_associate(PoolView pv, 
             sh_M = Mn;
             sh_lm = active ? idx : -1;
             assoc_out[j] = sh_lm;
+            if (active) sh_applied++;
             if (active) {                                // :331-381 with the FRESH pose
                 MeasTerms m;
                 measurement_terms(st[2 * idx + 3], st[2 * idx + 4], mx, my, st[0], st[1], st[2], m);
@@ -244,6 +246,37 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_associate(PoolView pv, 
         a.known_count = sh_M; a.lm = sh_lm; a.active = sh_lm >= 0; a.pad = 0; a.best = 0.0;
         pv.assoc[b] = a;
     }
+    __syncthreads();
+    return sh_applied;
+}
+
+__global__ __launch_bounds__(kSmallThreads) void k_small_associate(PoolView pv, const double* __restrict__ meas, int J,
+                                                                   int known_count_in, int* __restrict__ assoc_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    small_associate_body(pv, blockIdx.x, pv.N, meas, J, known_count_in, assoc_out, sm);
+}
+
+// The same for a whole pool and one step of an unknown-association log: filter b takes its count[b] readings,
+// continues from its own device-resident known_count, and works inside its own discovered prefix
+// N_b = max(min_active, 3 + 2*min(n, known_count + count)) -- everything beyond still holds constructor values,
+// where K and H*Sigma are exact zeros (see ekf_associate).  The host guarantees N_b <= small_max_dim() for
+// every filter of the launch (its bound is refreshed from the device), so one launch per STEP replaces
+// 4 launches per measurement slot.  assoc_out[b][jmax]: decisions; slots >= count keep -2.
+__global__ __launch_bounds__(kSmallThreads) void k_pool_associate(PoolView pv, const double* __restrict__ meas,
+                                                                  const int* __restrict__ count, int jmax,
+                                                                  int min_active, int* __restrict__ assoc_out,
+                                                                  unsigned long long* __restrict__ corr_counter) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = blockIdx.x;
+    const int J = count[b];
+    if (J <= 0) return;  // uniform
+    const int kc = pv.assoc[b].known_count;
+    int m = kc + J < pv.n ? kc + J : pv.n;
+    int N = 3 + 2 * m;
+    if (min_active > N) N = min_active;
+    if (N > pv.N) N = pv.N;  // pv.N = the launch's bound (sizes the LDS)
+    const int applied = small_associate_body(pv, b, N, meas + (size_t)b * jmax * 2, J, kc, assoc_out + (size_t)b * jmax, sm);
+    if (threadIdx.x == 0 && corr_counter && applied) atomicAdd(corr_counter, (unsigned long long)applied);
 }
 
 size_t small_lds_bytes(int N) { return sizeof(double) * ((size_t)N * (N | 1) + 3 * (size_t)N); }
@@ -253,8 +286,17 @@ hipError_t small_prepare() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_measure),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_associate),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_associate),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pool_associate),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
+}
+
+void launch_pool_associate(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
+                           int* assoc_out, unsigned long long* corr_counter, hipStream_t s) {
+    hipLaunchKernelGGL(k_pool_associate, dim3(pv.B), dim3(kSmallThreads), small_lds_bytes(pv.N), s, pv, meas, count, jmax,
+                       min_active, assoc_out, corr_counter);
 }
 
 void launch_small_associate(const PoolView& pv, const double* meas, int J, int known_count, int* assoc_out,

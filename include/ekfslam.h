@@ -105,6 +105,10 @@ ekf_status ekf_set_init_flag(ekf_handle h, int flag);
  * bit-identical to enable == 0 for finite states. */
 ekf_status ekf_set_active_prefix(ekf_handle h, int enable);
 ekf_status ekf_batch_set_active_prefix(ekf_batch_handle hb, int enable);
+/* ekf_batch_run_unknown: while every filter's discovered prefix fits the LDS-resident small-map path
+ * (3 + 2*(known_count + readings of the step) <= 104), one launch per step handles the whole pool
+ * (enable != 0, default).  enable == 0: always four launches per measurement slot.  Bit-identical. */
+ekf_status ekf_batch_set_small_map_path(ekf_batch_handle hb, int enable);
 /* Single filter, maps beyond the small-map path: every eager correction (gain K, state, covariance) runs as
  * ONE launch that writes Sigma - K(H Sigma) out of place into a second buffer; the two buffers swap after
  * each correction (enable != 0, default).  enable == 0: the two-launch form (gain, then the in-place rank-2

@@ -31,20 +31,28 @@ def test_batch_unknown_vs_oracle(hip, oracle):
     n, B, T = 20, 6, 60
     log = _ragged_log(n, B, T, 777, 6)
     assert len(set(log.count.reshape(-1).tolist())) > 2, "the slots must be ragged across filters"
-    bt = hip.BatchEKF(B, n)
-    bt.upload_unknown_log(log.twist, log.count, log.meas_xy)
-    st = bt.run_unknown(0, T, time_kernels=True)
-    dec, kc = bt.decisions(), bt.known_counts()
-    applied = 0
-    for b in range(B):
-        o, known, d = _oracle_replay(oracle, log, b, n, 0, T)
-        assert np.array_equal(dec[:, b], d), f"filter {b}: decisions differ"
-        assert kc[b] == int(known.sum()) and known[:kc[b]].all()
-        assert_parity(bt.state(b), bt.cov(b), o.state, o.cov, FP64_TOL, f"batch unknown, filter {b}")
-        applied += int((d >= 0).sum())
-    assert st["corrections"] == applied and applied > 100
-    assert st["filter_steps"] == B * T and st["rank2_launches"] == int(log.count.max(axis=1).sum())
-    bt.close()
+    snap = []
+    for small in (False, True):  # four launches per measurement slot / one LDS-resident launch per step (N = 43)
+        bt = hip.BatchEKF(B, n)
+        bt.set_small_map_path(small)
+        bt.upload_unknown_log(log.twist, log.count, log.meas_xy)
+        st = bt.run_unknown(0, T, time_kernels=True)
+        dec, kc = bt.decisions(), bt.known_counts()
+        applied = 0
+        for b in range(B):
+            o, known, d = _oracle_replay(oracle, log, b, n, 0, T)
+            assert np.array_equal(dec[:, b], d), f"filter {b}: decisions differ"
+            assert kc[b] == int(known.sum()) and known[:kc[b]].all()
+            assert_parity(bt.state(b), bt.cov(b), o.state, o.cov, FP64_TOL, f"batch unknown, filter {b}")
+            applied += int((d >= 0).sum())
+        assert st["corrections"] == applied and applied > 100
+        launches = int((log.count.max(axis=1) > 0).sum()) if small else int(log.count.max(axis=1).sum())
+        assert st["filter_steps"] == B * T and st["rank2_launches"] == launches
+        snap.append((dec.copy(), [bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)]))
+        bt.close()
+    assert np.array_equal(snap[0][0], snap[1][0])
+    for b in range(B):  # same arithmetic in the same order: bit-identical
+        assert np.array_equal(snap[0][1][b], snap[1][1][b]) and np.array_equal(snap[0][2][b], snap[1][2][b])
 
 
 def test_batch_unknown_split_runs_and_prefix_off(hip, oracle):
@@ -131,3 +139,46 @@ def test_batch_unknown_errors(hip):
     st = bt.run_unknown()
     assert st["corrections"] == 0 and st["rank2_launches"] == 0
     bt.close()
+
+
+def test_batch_unknown_outgrows_the_small_path(hip, oracle):
+    """Three new landmarks per step: the discovered prefix passes N = 104 mid-run, so the run switches from one
+    LDS-resident launch per step to four launches per slot -- and must not differ from the all-multi-launch run."""
+    n, B, T, J = 90, 2, 34, 5
+    rng = np.random.default_rng(12)
+    grid = np.array([[0.6 * (k % 12) - 3.27, 0.6 * (k // 12) - 2.03] for k in range(120)])
+    twist = np.zeros((T, B, 2)); twist[:, :, 1] = 0.002; twist[:, 1, 0] = 0.001
+    count = np.zeros((T, B), dtype=np.int32)
+    meas = np.zeros((T, B, J, 2))
+    for t in range(T):
+        new = [3 * t, 3 * t + 1, 3 * t + 2]
+        old = [t, (2 * t) // 3] if t > 0 else []
+        ids = new + old
+        count[t, 0] = len(ids)
+        meas[t, 0, :len(ids)] = grid[ids] + rng.normal(0, 0.003, (len(ids), 2))
+        ids1 = (old + new)[:4]          # ragged: other order, one reading fewer
+        count[t, 1] = len(ids1)
+        meas[t, 1, :len(ids1)] = grid[ids1] + rng.normal(0, 0.003, (len(ids1), 2))
+    log = type("L", (), {"twist": twist, "count": count, "meas_xy": meas})
+    snap = []
+    for small in (True, False):
+        bt = hip.BatchEKF(B, n)
+        bt.set_small_map_path(small)
+        bt.upload_unknown_log(twist, count, meas)
+        st = bt.run_unknown(0, 20)
+        st2 = bt.run_unknown(20, T)
+        launches = st["rank2_launches"] + st2["rank2_launches"]
+        if small:  # early steps took the one-launch form, late ones (known_count + readings > 50) could not
+            assert T < launches < int(count.max(axis=1).sum())
+        else:
+            assert launches == int(count.max(axis=1).sum())
+        snap.append((bt.decisions().copy(), bt.known_counts().copy(), [bt.state(b) for b in range(B)],
+                     [bt.cov(b) for b in range(B)]))
+        bt.close()
+    assert np.array_equal(snap[0][0], snap[1][0]) and np.array_equal(snap[0][1], snap[1][1])
+    assert snap[0][1].max() > 52  # N_b > 104: beyond the small path
+    for b in range(B):
+        assert np.array_equal(snap[0][2][b], snap[1][2][b]) and np.array_equal(snap[0][3][b], snap[1][3][b])
+    o, known, d = _oracle_replay(oracle, log, 0, n, 0, T)
+    assert np.array_equal(snap[0][0][:, 0], d)
+    assert_parity(snap[0][2][0], snap[0][3][0], o.state, o.cov, FP64_TOL, "outgrowing the small path")
