@@ -1007,7 +1007,24 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
     src.mode = ekf::SRC_COMPACT_LOG;
     src.vmax = vmax;
     src.fresh_pose = 0;
-    for (int t = t_begin; t < t_end; t++) {
+    // Small maps (the reference's own n = 20): the whole step range in ONE launch, every filter's Sigma resident
+    // in LDS from the first step to the last (k_pool_run_known); bit-identical to the replay below.
+    const bool small_run = P.small_path && !delayed && !P.active_set && P.pv.n > 0 && P.pv.N <= ekf::small_max_dim() &&
+                           vmax <= 64 && t_end > t_begin;
+    if (small_run) {
+        if (ev) HIPC(hipEventRecord(ev[0], P.stream));
+        ekf::launch_pool_run_known(P.pv, P.log_twist, P.log_lm, P.log_z, P.log_init, vmax, t_begin, t_end, !P.init_flag,
+                                   P.stream);
+        if (ev) HIPC(hipEventRecord(ev[1], P.stream));
+        k = 1;
+        P.init_flag = 1;
+        if ((size_t)(t_end - 1) < P.log_touch_bound.size()) {
+            int cand = P.touch_bound_base + P.log_touch_bound[t_end - 1];
+            if (cand > P.pv.n) cand = P.pv.n;
+            if (cand > P.touched_bound) P.touched_bound = cand;
+        }
+    }
+    for (int t = small_run ? t_end : t_begin; t < t_end; t++) {
         ekf::launch_predict(P.pv, P.log_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream);  // prediction()
         ekf::launch_measure_begin(P.pv, P.log_init, !P.init_flag, P.stream);               // measurement() top
         P.init_flag = 1;

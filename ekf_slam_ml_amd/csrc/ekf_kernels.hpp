@@ -236,6 +236,10 @@ void launch_small_associate(const PoolView& pv, const double* meas, int J, int k
 // pv.N = the pool-wide bound of 3 + 2*(known_count + count) (<= small_max_dim()); meas [B][jmax][2], count [B]
 void launch_pool_associate(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                            int* assoc_out /*[B][jmax]*/, unsigned long long* corr_counter, hipStream_t s);
+// steps [t0, t1) of a compact known-association log for a pool of small maps (pv.N <= small_max_dim(),
+// vmax <= 64) in one launch, Sigma resident in LDS throughout (log layout as ekf_known_log)
+void launch_pool_run_known(const PoolView& pv, const double* twist, const int* lm_idx, const double* z_xy,
+                           const double* init_xy, int vmax, int t0, int t1, int do_init, hipStream_t s);
 int small_max_dim();          // largest N = 3 + 2n the small path accepts
 hipError_t small_prepare();   // raises the kernel's dynamic-LDS limit (87 KB > 64 KB default)
 int max_pending();  // capacity limit of the delayed-update factor store (rows of U / V per filter)

@@ -104,17 +104,17 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_measure(PoolView pv, co
 
 // ---------------------------------------------------------------------------------------------
 // data_association() of a small map in ONE launch (ekf_slam.cpp:278-402): for every measurement, in order,
-// the Mahalanobis scores of the known landmarks (one landmark per WAVEFRONT: the 25-lane gather and the
-// shuffle folds of k_maha, fed from LDS), the sequential-scan decision with its two gates and the
+// the Mahalanobis scores of the known landmarks (one landmark per LANE here -- everything a score needs is in
+// LDS, and innovation_cov() sums in the order of k_maha's shuffle folds), the sequential-scan decision with its two gates and the
 // new-landmark initialisation (k_assoc_decide), and the correction with the fresh pose (k_gain + k_rank2).
 // Same arithmetic as the multi-kernel chain -> bit-identical results and decisions.
 // ---------------------------------------------------------------------------------------------
 // N: the filter's active dimension (the leading N x N block of Sigma is all these J measurements can touch);
 // returns (on every lane) the number of corrections applied.
+template <int THREADS>
 __device__ int small_associate_body(const PoolView& pv, int b, int N, const double* __restrict__ meas, int J,
                                     int known_count_in, int* __restrict__ assoc_out, double* sm) {
     const int tid = threadIdx.x;
-    const int wave = tid / kWave, lane = tid % kWave;
     const int ld = pv.ld, n = pv.n;
     const int ldS = N | 1;
     double* S = sm;
@@ -126,45 +126,29 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
 
     double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
     double* stg = pv.state + (size_t)b * ld;
-    for (int r = tid >> 6; r < N; r += kSmallThreads / 64)
+    for (int r = tid >> 6; r < N; r += THREADS / 64)
         for (int c = tid & 63; c < N; c += 64) S[r * ldS + c] = Sg[(size_t)r * ld + c];
-    for (int r = tid; r < N; r += kSmallThreads) st[r] = stg[r];
+    for (int r = tid; r < N; r += THREADS) st[r] = stg[r];
     if (tid == 0) { sh_M = known_count_in; sh_applied = 0; }
     __syncthreads();
 
     for (int j = 0; j < J; j++) {                       // :291 sequential, state-carrying
         const double mx = meas[2 * j], my = meas[2 * j + 1];
         const int M = sh_M;
-        for (int i = wave; i < M; i += kSmallThreads / kWave) {   // :300-309, one landmark per wavefront
-            double v = 0.0;
-            if (lane < 25) v = S[idx5(lane / 5, i) * ldS + idx5(lane % 5, i)];
+        for (int i = tid; i < M; i += THREADS) {          // :300-309, one landmark per LANE, all from LDS
             MeasTerms m;                                 // fresh pose per score, :219-221
             measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, st[0], st[1], st[2], m);
-            const int l5 = lane < 5 ? lane : 4;
-            double hs0 = 0.0, hs1 = 0.0;
+            double S55[5][5], Sm[2][2], Si[2][2];
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const double vk = __shfl(v, k * 5 + l5, kWave);
-                hs0 += m.H[0][k] * vk;
-                hs1 += m.H[1][k] * vk;
-            }
-            double Sm[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+            for (int k = 0; k < 5; k++)
 #pragma unroll
-            for (int l = 0; l < 5; l++) {
-                const double h0 = __shfl(hs0, l, kWave), h1 = __shfl(hs1, l, kWave);
-                Sm[0][0] += h0 * m.H[0][l];
-                Sm[0][1] += h0 * m.H[1][l];
-                Sm[1][0] += h1 * m.H[0][l];
-                Sm[1][1] += h1 * m.H[1][l];
-            }
-            Sm[0][0] += pv.p.r_meas;
-            Sm[1][1] += pv.p.r_meas;
-            double Si[2][2];
+                for (int l = 0; l < 5; l++) S55[k][l] = S[idx5(k, i) * ldS + idx5(l, i)];
+            innovation_cov(S55, m.H, pv.p.r_meas, Sm);   // same summation order as k_maha's shuffle folds
             inv2(Sm, Si);
             const double v0 = m.z0 - m.zh0, v1 = m.z1 - m.zh1;   // bearing NOT wrapped, :269
             const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
             const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
-            if (lane == 0) sh_score[i] = t0 * v0 + t1 * v1;
+            sh_score[i] = t0 * v0 + t1 * v1;
         }
         __syncthreads();
         if (tid == 0) {                                  // :293-330
@@ -238,9 +222,9 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
         __syncthreads();
     }
 
-    for (int r = tid >> 6; r < N; r += kSmallThreads / 64)
+    for (int r = tid >> 6; r < N; r += THREADS / 64)
         for (int c = tid & 63; c < N; c += 64) Sg[(size_t)r * ld + c] = S[r * ldS + c];
-    for (int r = tid; r < N; r += kSmallThreads) stg[r] = st[r];
+    for (int r = tid; r < N; r += THREADS) stg[r] = st[r];
     if (tid == 0) {
         AssocRec a;
         a.known_count = sh_M; a.lm = sh_lm; a.active = sh_lm >= 0; a.pad = 0; a.best = 0.0;
@@ -250,10 +234,11 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
     return sh_applied;
 }
 
-__global__ __launch_bounds__(kSmallThreads) void k_small_associate(PoolView pv, const double* __restrict__ meas, int J,
-                                                                   int known_count_in, int* __restrict__ assoc_out) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_small_associate(PoolView pv, const double* __restrict__ meas, int J,
+                                                             int known_count_in, int* __restrict__ assoc_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    small_associate_body(pv, blockIdx.x, pv.N, meas, J, known_count_in, assoc_out, sm);
+    small_associate_body<THREADS>(pv, blockIdx.x, pv.N, meas, J, known_count_in, assoc_out, sm);
 }
 
 // The same for a whole pool and one step of an unknown-association log: filter b takes its count[b] readings,
@@ -262,10 +247,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_associate(PoolView pv, 
 // where K and H*Sigma are exact zeros (see ekf_associate).  The host guarantees N_b <= small_max_dim() for
 // every filter of the launch (its bound is refreshed from the device), so one launch per STEP replaces
 // 4 launches per measurement slot.  assoc_out[b][jmax]: decisions; slots >= count keep -2.
-__global__ __launch_bounds__(kSmallThreads) void k_pool_associate(PoolView pv, const double* __restrict__ meas,
-                                                                  const int* __restrict__ count, int jmax,
-                                                                  int min_active, int* __restrict__ assoc_out,
-                                                                  unsigned long long* __restrict__ corr_counter) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_pool_associate(PoolView pv, const double* __restrict__ meas,
+                                                            const int* __restrict__ count, int jmax, int min_active,
+                                                            int* __restrict__ assoc_out,
+                                                            unsigned long long* __restrict__ corr_counter) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x;
     const int J = count[b];
@@ -275,8 +261,186 @@ __global__ __launch_bounds__(kSmallThreads) void k_pool_associate(PoolView pv, c
     int N = 3 + 2 * m;
     if (min_active > N) N = min_active;
     if (N > pv.N) N = pv.N;  // pv.N = the launch's bound (sizes the LDS)
-    const int applied = small_associate_body(pv, b, N, meas + (size_t)b * jmax * 2, J, kc, assoc_out + (size_t)b * jmax, sm);
+    const int applied = small_associate_body<THREADS>(pv, b, N, meas + (size_t)b * jmax * 2, J, kc, assoc_out + (size_t)b * jmax, sm);
     if (threadIdx.x == 0 && corr_counter && applied) atomicAdd(corr_counter, (unsigned long long)applied);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A whole RANGE OF STEPS of a known-association log for a pool of small maps in ONE launch: workgroup b keeps
+// filter b's Sigma and state in LDS from the first to the last step -- prediction() (ekf_slam.cpp:55-106, the
+// structured arithmetic of k_predict), the top of measurement() (:109-128) and every logged correction
+// (:132-194, the arithmetic of k_small_measure) -- so HBM sees the log once and Sigma twice per run instead of
+// (2 + 2V) launches per step.  This is the reference's own operating point (n = 20) at Monte-Carlo scale.
+// Bit-identical to the multi-kernel replay.  The next step's log slots are fetched while the current step runs.
+// ---------------------------------------------------------------------------------------------
+// THREADS: one lane per row of Sigma, so 64 (a single wavefront, N <= 64: the n = 20 case) or 128.  With 256-thread
+// workgroups only wave 0 of each would carry rows, and the wave 0s of all resident workgroups share a SIMD.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_pool_run_known(PoolView pv, const double* __restrict__ twist,
+                                                                  const int* __restrict__ lm_idx,
+                                                                  const double* __restrict__ z_xy,
+                                                                  const double* __restrict__ init_xy, int vmax,
+                                                                  int t0, int t1, int do_init) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, B = pv.B;
+    const int N = pv.N, ld = pv.ld, n = pv.n;
+    const int ldS = N | 1;
+    double* S = sm;                    // [N][ldS]
+    double* st = S + (size_t)N * ldS;  // [N]
+    double* Gg = st + N;               // [2][N]
+    __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
+    __shared__ double sh_tw[2], sh_z[2 * 64];
+    __shared__ int sh_lmv[64];
+
+    double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    double* stg = pv.state + (size_t)b * ld;
+    for (int r = tid >> 6; r < N; r += THREADS / 64)
+        for (int c = tid & 63; c < N; c += 64) S[r * ldS + c] = Sg[(size_t)r * ld + c];
+    for (int r = tid; r < N; r += THREADS) st[r] = stg[r];
+
+    // log slots of step t for this filter, one slot per lane (vmax <= 64)
+    int lm_n = -1;
+    double zx_n = 0.0, zy_n = 0.0, tw_n = 0.0;
+    auto fetch = [&](int t) {
+        if (t < t1) {
+            const size_t slot = ((size_t)t * B + b) * vmax + tid;
+            if (tid < vmax) { lm_n = lm_idx[slot]; zx_n = z_xy[slot * 2]; zy_n = z_xy[slot * 2 + 1]; }
+            if (tid < 2) tw_n = twist[((size_t)t * B + b) * 2 + tid];
+        }
+    };
+    fetch(t0);
+
+    for (int t = t0; t < t1; t++) {
+        __syncthreads();  // previous step done with sh_lmv / sh_z / sh_tw; first trip: LDS image complete
+        if (tid < vmax) { sh_lmv[tid] = lm_n; sh_z[2 * tid] = zx_n; sh_z[2 * tid + 1] = zy_n; }
+        if (tid < 2) sh_tw[tid] = tw_n;
+        __syncthreads();
+        fetch(t + 1);  // flies under this step's arithmetic
+
+        // ---- prediction(), ekf_slam.cpp:55-106 (k_predict) ----
+        {
+            const double dtheta = sh_tw[0], dx = sh_tw[1];
+            const double theta = st[0];
+            double u0, u1, u2, a10, a20;
+            if (fabs(dtheta) < pv.p.straight_eps) {  // :79-86
+                u0 = 0;
+                u1 = dx * cos(theta);
+                u2 = dx * sin(theta);
+                a10 = -dx * sin(theta);
+                a20 = dx * cos(theta);
+            } else {  // :88-94
+                u0 = dtheta;
+                u1 = -(dx / dtheta) * sin(theta) + (dx / dtheta) * sin(theta + dtheta);
+                u2 = (dx / dtheta) * cos(theta) - (dx / dtheta) * cos(theta + dtheta);
+                a10 = -(dx / dtheta) * cos(theta) + (dx / dtheta) * cos(theta + dtheta);
+                a20 = -(dx / dtheta) * sin(theta) + (dx / dtheta) * sin(theta + dtheta);
+            }
+            double c[3][3], px = 0.0, py = 0.0;
+            if (tid == 0) {
+                for (int r = 0; r < 3; r++)
+                    for (int k = 0; k < 3; k++) c[r][k] = S[r * ldS + k];
+                px = st[1]; py = st[2];
+            }
+            __syncthreads();  // all threads hold the old theta; thread 0 may now move the pose
+            for (int k = 3 + tid; k < N; k += THREADS) {
+                const double q0 = S[0 * ldS + k], q1 = S[1 * ldS + k], q2 = S[2 * ldS + k];
+                double* rowk = S + k * ldS;
+                const double r0 = rowk[0], r1 = rowk[1], r2 = rowk[2];
+                S[1 * ldS + k] = a10 * q0 + q1;
+                S[2 * ldS + k] = a20 * q0 + q2;
+                rowk[1] = r0 * a10 + r1;
+                rowk[2] = r0 * a20 + r2;
+            }
+            if (tid == 0) {
+                st[0] = theta + u0;  // :99 -- theta is NOT wrapped after the prediction
+                st[1] = px + u1;
+                st[2] = py + u2;
+                double T[3][3];
+                for (int k = 0; k < 3; k++) {
+                    T[0][k] = c[0][k];
+                    T[1][k] = a10 * c[0][k] + c[1][k];
+                    T[2][k] = a20 * c[0][k] + c[2][k];
+                }
+                for (int r = 0; r < 3; r++) {
+                    S[r * ldS + 0] = T[r][0];
+                    S[r * ldS + 1] = T[r][0] * a10 + T[r][1];
+                    S[r * ldS + 2] = T[r][0] * a20 + T[r][2];
+                }
+                S[0] += pv.p.q_pose;  // Q = diag(q,q,q,0...) :40-43
+                S[1 * ldS + 1] += pv.p.q_pose;
+                S[2 * ldS + 2] += pv.p.q_pose;
+            }
+            __syncthreads();
+        }
+
+        // ---- measurement(), ekf_slam.cpp:108-197 ----
+        const double theta = st[0], x = st[1], y = st[2];  // captured ONCE per call, :109-111
+        if (do_init) {                                     // first call only, :113-128
+            __syncthreads();
+            const double* sens = init_xy + (size_t)b * 2 * n;
+            for (int i = tid; i < n; i += THREADS) {
+                const double sx = sens[2 * i], sy = sens[2 * i + 1];
+                const double ri = sqrt(sx * sx + sy * sy);
+                const double phii = atan2(sy, sx);
+                st[2 * i + 3] = x + ri * cos(phii + theta);
+                st[2 * i + 3 + 1] = y + ri * sin(phii + theta);
+            }
+            do_init = 0;
+            __syncthreads();
+        }
+        for (int v = 0; v < vmax; v++) {  // :132-194, ascending landmark order, -1 padded
+            const int lm = sh_lmv[v];
+            if (lm < 0) break;            // uniform
+            if (tid == 0) {
+                MeasTerms m;
+                measurement_terms(st[2 * lm + 3], st[2 * lm + 4], sh_z[2 * v], sh_z[2 * v + 1], theta, x, y, m);
+                double S55[5][5], Sm[2][2], Si[2][2];
+                for (int k = 0; k < 5; k++)
+                    for (int l = 0; l < 5; l++) S55[k][l] = S[idx5(k, lm) * ldS + idx5(l, lm)];
+                innovation_cov(S55, m.H, pv.p.r_meas, Sm);
+                inv2(Sm, Si);
+                for (int a = 0; a < 2; a++)
+                    for (int k = 0; k < 5; k++) sh_H[a * 5 + k] = m.H[a][k];
+                sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
+                sh_nu[0] = m.z0 - m.zh0;                   // :182
+                sh_nu[1] = normalize_angle(m.z1 - m.zh1);  // :183
+                touch_landmark(pv, b, lm);
+            }
+            __syncthreads();
+            double k0 = 0.0, k1 = 0.0;
+            const int r = tid;
+            if (r < N) {
+                double sht0 = 0.0, sht1 = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const int c = idx5(k, lm);
+                    const double p = S[r * ldS + c];
+                    const double g = S[c * ldS + r];
+                    sht0 += p * sh_H[k];
+                    sht1 += p * sh_H[5 + k];
+                    g0 += sh_H[k] * g;
+                    g1 += sh_H[5 + k] * g;
+                }
+                k0 = sht0 * sh_Si[0] + sht1 * sh_Si[2];  // :178
+                k1 = sht0 * sh_Si[1] + sht1 * sh_Si[3];
+                Gg[r] = g0;
+                Gg[N + r] = g1;
+            }
+            __syncthreads();
+            if (r < N) {
+                double* row = S + r * ldS;
+                for (int c = 0; c < N; c++) row[c] = row[c] - (k0 * Gg[c] + k1 * Gg[N + c]);  // :191-192
+                double s = st[r] + (k0 * sh_nu[0] + k1 * sh_nu[1]);                             // :186
+                if (r == 0) s = normalize_angle(s);                                             // :187
+                st[r] = s;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int r = tid >> 6; r < N; r += THREADS / 64)
+        for (int c = tid & 63; c < N; c += 64) Sg[(size_t)r * ld + c] = S[r * ldS + c];
+    for (int r = tid; r < N; r += THREADS) stg[r] = st[r];
 }
 
 size_t small_lds_bytes(int N) { return sizeof(double) * ((size_t)N * (N | 1) + 3 * (size_t)N); }
@@ -286,23 +450,52 @@ hipError_t small_prepare() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_measure),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_associate),
+    for (const void* f : {reinterpret_cast<const void*>(&k_small_associate<64>),
+                          reinterpret_cast<const void*>(&k_small_associate<128>),
+                          reinterpret_cast<const void*>(&k_pool_associate<64>),
+                          reinterpret_cast<const void*>(&k_pool_associate<128>)}) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
+        if (e != hipSuccess) return e;
+    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pool_run_known<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(64));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pool_run_known<128>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pool_associate),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
+    return hipSuccess;
+}
+
+void launch_pool_run_known(const PoolView& pv, const double* twist, const int* lm_idx, const double* z_xy,
+                           const double* init_xy, int vmax, int t0, int t1, int do_init, hipStream_t s) {
+    if (pv.N <= 64)
+        hipLaunchKernelGGL(k_pool_run_known<64>, dim3(pv.B), dim3(64), small_lds_bytes(pv.N), s, pv, twist, lm_idx, z_xy,
+                           init_xy, vmax, t0, t1, do_init);
+    else
+        hipLaunchKernelGGL(k_pool_run_known<128>, dim3(pv.B), dim3(128), small_lds_bytes(pv.N), s, pv, twist, lm_idx, z_xy,
+                           init_xy, vmax, t0, t1, do_init);
 }
 
 void launch_pool_associate(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                            int* assoc_out, unsigned long long* corr_counter, hipStream_t s) {
-    hipLaunchKernelGGL(k_pool_associate, dim3(pv.B), dim3(kSmallThreads), small_lds_bytes(pv.N), s, pv, meas, count, jmax,
-                       min_active, assoc_out, corr_counter);
+    // one lane per row of the prefix: a single wavefront while N <= 64 (wave 0 of a 256-thread workgroup would carry
+    // all rows, and the wave 0s of the resident workgroups share one SIMD)
+    if (pv.N <= 64)
+        hipLaunchKernelGGL(k_pool_associate<64>, dim3(pv.B), dim3(64), small_lds_bytes(pv.N), s, pv, meas, count, jmax,
+                           min_active, assoc_out, corr_counter);
+    else
+        hipLaunchKernelGGL(k_pool_associate<128>, dim3(pv.B), dim3(128), small_lds_bytes(pv.N), s, pv, meas, count, jmax,
+                           min_active, assoc_out, corr_counter);
 }
 
 void launch_small_associate(const PoolView& pv, const double* meas, int J, int known_count, int* assoc_out,
                             hipStream_t s) {
-    hipLaunchKernelGGL(k_small_associate, dim3(pv.B), dim3(kSmallThreads), small_lds_bytes(pv.N), s, pv, meas, J,
-                       known_count, assoc_out);
+    if (pv.N <= 64)
+        hipLaunchKernelGGL(k_small_associate<64>, dim3(pv.B), dim3(64), small_lds_bytes(pv.N), s, pv, meas, J, known_count,
+                           assoc_out);
+    else
+        hipLaunchKernelGGL(k_small_associate<128>, dim3(pv.B), dim3(128), small_lds_bytes(pv.N), s, pv, meas, J,
+                           known_count, assoc_out);
 }
 
 void launch_small_measure(const PoolView& pv, const double* sensor, const unsigned char* visible, int do_init,
