@@ -38,6 +38,7 @@ def parse():
                     help="also time the delayed rank-2k update with this many corrections per flush (0 = skip)")
     ap.add_argument("--no-active-set", action="store_true", help="skip the active-set leg")
     ap.add_argument("--no-unknown", action="store_true", help="skip the batched unknown-association leg")
+    ap.add_argument("--no-small", action="store_true", help="skip the small-map (n = 20) Monte-Carlo leg")
     ap.add_argument("--host-log", action="store_true",
                     help="generate the synthetic log on the host (numpy) and upload it, instead of on the device")
     ap.add_argument("--rows", type=int, default=0)
@@ -288,6 +289,32 @@ def main():
                 "note": "configs[2]'s world and sensor for every filter of the pool; landmarks are appended in discovery "
                         "order, so each filter's corrections stream only its leading 3 + 2*known block (bit-identical "
                         "to the full-width update, tests/test_gpu_batch_unknown.py)"}
+    # The reference's own operating point at Monte-Carlo scale: configs[0] (n = 20, 1000 steps) for 8192 robots per
+    # GPU, inputs simulated on the device, the whole run ONE launch with every covariance resident in LDS.
+    if not a.no_small and not a.host_log:
+        Bs, Ts, ns = 8192, 1000, 20
+        scfg = synth.config1(steps=Ts)
+        scfg.filters, scfg.first_filter_id = Bs, rank * Bs
+        sworld = synth.make_world(ns, scfg.half_extent, scfg.min_spacing, scfg.seed)
+        sb = capi.BatchEKF(Bs, ns, device=local)
+        sb.simulate_known_log(scfg, sworld, vmax=ns)
+        sb.run_known(0, 1)  # the first call initialises the map (ekf_slam.cpp:113-128)
+        fence()
+        t0 = time.perf_counter()
+        ss = sb.run_known(1, Ts, time_kernels=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fence()
+        swall, scorr, ssteps = shard.reduce_throughput(t1 - t0, float(ss["corrections"]), float(ss["filter_steps"]),
+                                                       device=red_dev)
+        if rank == 0:
+            out["small_map_monte_carlo"] = {
+                "value": ssteps / swall, "unit": "filter steps/s (1 step = prediction + measurement of the visible landmarks)",
+                "corrections_per_s": scorr / swall, "filters_per_gpu": Bs, "landmarks": ns, "steps": Ts - 1,
+                "launches": ss["rank2_launches"], "mc_consistency": sb.mc_stats(Ts - 1),
+                "note": "BASELINE.json configs[0] (the reference's n = 20 known-association run) for every filter; "
+                        "bit-identical to the per-step replay (tests/test_gpu_pool_small.py)"}
+        sb.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     bt.close()
