@@ -13,7 +13,7 @@ out = sys.argv[1]
 
 def find(sub, pat):
     hits = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None  # gpurun merges runs: take the latest
 
 
 def bench_line(name):
@@ -35,7 +35,7 @@ if stats:
     for r in rows:
         print(f"{r['Name'][:90]:90s} calls {r['Calls']:>6s} total_ms {float(r['TotalDurationNs']) / 1e6:10.3f} "
               f"avg_us {float(r['AverageNs']) / 1e3:12.2f} pct {r['Percentage']}")
-        if "k_rank2" in r["Name"]:
+        if "k_rank2<" in r["Name"]:
             summary["rank2_avg_ms_rocprof"] = float(r["AverageNs"]) / 1e6
             summary["rank2_calls"] = int(r["Calls"])
 b = bench_line("bench_trace.json")
@@ -51,7 +51,7 @@ def counter(sub, cname):
         return None
     tot, cnt = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if r.get("Counter_Name") == cname and "k_rank2" in r.get("Kernel_Name", ""):
+        if r.get("Counter_Name") == cname and "k_rank2<" in r.get("Kernel_Name", ""):
             tot += float(r["Counter_Value"])
             cnt += 1
     return (tot / cnt, cnt) if cnt else None
