@@ -245,8 +245,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             # the box's CPU share for a one-GPU job is 16 cores (the machine reports all 256)
             cores = int(os.environ.get("EKF_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
-            # bounded sample: ~10 s of CPU work incl. the untimed warm-up (each filter is 32 MB of covariance)
-            Bc = a.cpu_filters if a.cpu_filters > 0 else min(B, 48 * cores)
+            # bounded sample: ~10 s of CPU work incl. the untimed warm-up (each filter is 32 MB of covariance: 82 GB)
+            Bc = a.cpu_filters if a.cpu_filters > 0 else min(B, 160 * cores)
             import copy
             cfg_c = copy.copy(cfg)
             cfg_c.filters = Bc
