@@ -1,0 +1,473 @@
+// ekf_runtime.hpp -- host runtime shared by the C-ABI translation units (ekf_capi*.hip): error reporting,
+// pinned staging, and Pool = the device state of B filters (covariance pool, scratch, logs, update-mode
+// bookkeeping) with its stream-ordered helpers.  No CPU fallback exists: without a gfx950 device every
+// entry point fails with EKF_ERR_NO_DEVICE.
+#pragma once
+#include "../../include/ekfslam.h"
+#include "ekf_kernels.hpp"
+#include "ekf_dense.hpp"
+#include "ekf_sim.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace ekfrt {
+
+inline thread_local std::string g_err;
+
+inline ekf_status fail(ekf_status st, const std::string& msg) {
+    g_err = msg;
+    return st;
+}
+
+#define HIPC(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(e_ == hipErrorOutOfMemory ? EKF_ERR_NOMEM : EKF_ERR_HIP,                \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+#define EKFC(expr)                        \
+    do {                                  \
+        ekf_status s_ = (expr);           \
+        if (s_ != EKF_OK) return s_;      \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// pinned host buffer whose last async use is guarded by an event
+struct Staging {
+    void* host = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+
+    ekf_status reserve(size_t need) {
+        if (need <= bytes) return EKF_OK;
+        EKFC(wait());
+        if (host) HIPC(hipHostFree(host));
+        host = nullptr; bytes = 0;
+        HIPC(hipHostMalloc(&host, need, hipHostMallocDefault));
+        bytes = need;
+        if (!ev) HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        return EKF_OK;
+    }
+    ekf_status wait() {
+        if (pending) { HIPC(hipEventSynchronize(ev)); pending = false; }
+        return EKF_OK;
+    }
+    ekf_status mark(hipStream_t s) {
+        HIPC(hipEventRecord(ev, s));
+        pending = true;
+        return EKF_OK;
+    }
+    void release() {
+        if (host) (void)hipHostFree(host);
+        if (ev) (void)hipEventDestroy(ev);
+        host = nullptr; ev = nullptr; bytes = 0; pending = false;
+    }
+};
+
+// ring of pinned staging buffers: an upload only waits for the copy issued kRing uploads ago, so the
+// host keeps queueing work while the GPU is still busy with earlier calls
+struct StagingRing {
+    static constexpr int kRing = 8;
+    Staging slot[kRing];
+    int next = 0;
+    Staging& acquire() {
+        Staging& s = slot[next];
+        next = (next + 1) % kRing;
+        return s;
+    }
+    void release() { for (Staging& s : slot) s.release(); }
+};
+
+struct Pool {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    ekf::PoolView pv{};
+    ekf::Rank2Tuning tuning{0, -1, 0};
+    size_t dev_bytes = 0;
+    int init_flag = 0;  // landmark_init_flag, ekf_slam.hpp:65
+
+    // association / single-filter staging (device)
+    double* scores = nullptr;    // [B][n]
+    double* meas_dev = nullptr;  // [jcap][2]
+    int* assoc_out_dev = nullptr;  // [jcap]
+    int jcap = 0;
+    double* sensor_dev = nullptr;  // [2n] (single filter)
+    double* digest_dev = nullptr;  // [B][4]
+    double* poses_dev = nullptr;   // [B][3]
+    StagingRing stage_in;
+    Staging stage_out;
+
+    // uploaded known-association log (device) + per-(step, slot) active-filter counts (host)
+    int T = 0, vmax = 0;
+    double* log_twist = nullptr;
+    int* log_lm = nullptr;
+    double* log_z = nullptr;
+    double* log_init = nullptr;
+    double* log_truth = nullptr;  // [T][B][3], simulated logs only
+    size_t log_bytes = 0;
+    std::vector<int> slot_active;  // [T][vmax]
+
+    // uploaded unknown-association log
+    int uT = 0, ujmax = 0;
+    double* ulog_twist = nullptr;  // [T][B][2]
+    int* ulog_count = nullptr;     // [T][B]
+    double* ulog_meas = nullptr;   // [T][B][jmax][2]
+    int* ulog_assoc = nullptr;     // [T][B][jmax] decisions
+    double* ulog_truth = nullptr;  // [T][B][3], simulated logs only
+    int truth_is_unknown_log = 0;  // which simulated log ekf_batch_mc_stats refers to (the latest)
+    unsigned long long* corr_counter = nullptr;
+    std::vector<int> ucount_host;  // [T][B]
+    size_t ulog_bytes = 0;
+
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+    // delayed rank-2k update (0 = eager): pending factor store + ping-pong state buffer
+    double* Uf = nullptr;
+    double* Vf = nullptr;
+    double* state_alt = nullptr;
+    int pend_cap = 0, pend_count = 0;
+    int pend_symmetric = 0;
+    int active_prefix = 1;  // data_association(): restrict corrections to the discovered prefix of the state
+    int touched_hwm = 0;    // landmarks [0, touched_hwm) may carry non-constructor covariance (single filter)
+    int small_path = 1;     // measurement() of a small map runs as one LDS-resident launch (ekf_small.hip)
+    int active_set = 0;     // eager corrections stream only the rows of the touched set (opt-in)
+    int touched_bound = 0;  // host-side upper bound of the device touch_count over the pool
+    std::vector<unsigned char> host_touched;  // single filter: exact host copy of the touched flags
+    std::vector<int> log_touch_bound;         // batch: bound after step t of the uploaded log
+    int touch_bound_base = 0;                 // touched_bound when that log arrived (filters may not be fresh)
+    unsigned char* visible_dev = nullptr;  // [n] (single filter)
+
+    // fused single-launch correction (single filter): the second covariance / state buffer it writes into
+    int fused = 1;
+    double* sigma_alt = nullptr;
+    double* state_fz = nullptr;
+    bool alt_synced = false;  // sigma_alt equals sigma outside the region the next fused correction rewrites
+
+    bool fused_ok() const { return fused && pv.B == 1 && pend_cap == 0 && !active_set; }
+    ekf_status ensure_alt() {
+        if (!sigma_alt) {
+            EKFC(dalloc(&sigma_alt, (size_t)pv.B * pv.sigma_stride));
+            EKFC(dalloc(&state_fz, (size_t)pv.B * pv.ld));
+            alt_synced = false;
+        }
+        if (!alt_synced) {
+            // Both buffers must agree wherever a (prefix-confined) correction does not write.  Anything that
+            // rewrites Sigma in place outside this path clears alt_synced; prediction() needs no copy -- beyond
+            // the discovered prefix it maps zeros to zeros, inside it the next fused correction rewrites all.
+            HIPC(hipMemcpyAsync(sigma_alt, pv.sigma, sizeof(double) * pv.B * pv.sigma_stride, hipMemcpyDeviceToDevice, stream));
+            alt_synced = true;
+        }
+        return EKF_OK;
+    }
+
+    ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count, pend_symmetric}; }
+
+    ekf_status set_update_mode(int max_pending_corrections, int symmetric_gather) {
+        EKFC(use());
+        EKFC(flush());
+        pend_symmetric = symmetric_gather ? 1 : 0;
+        HIPC(hipStreamSynchronize(stream));
+        for (double** p : {&Uf, &Vf, &state_alt})
+            if (*p) { HIPC(hipFree(*p)); *p = nullptr; }
+        pend_cap = 0;
+        if (max_pending_corrections <= 0) return EKF_OK;
+        int cap = 2 * max_pending_corrections;
+        if (cap > ekf::max_pending()) cap = ekf::max_pending();
+        const size_t cnt = (size_t)pv.B * cap * pv.ld;
+        HIPC(hipMalloc((void**)&Uf, cnt * sizeof(double)));
+        HIPC(hipMalloc((void**)&Vf, cnt * sizeof(double)));
+        HIPC(hipMalloc((void**)&state_alt, (size_t)pv.B * pv.ld * sizeof(double)));
+        HIPC(hipMemsetAsync(state_alt, 0, (size_t)pv.B * pv.ld * sizeof(double), stream));
+        pend_cap = cap;
+        return EKF_OK;
+    }
+
+    // fold every pending correction into Sigma_base (no-op in eager mode)
+    ekf_status flush() {
+        if (pend_count > 0) {
+            alt_synced = false;
+            ekf::launch_flush(pv, pending(), tuning, stream);
+            HIPC(hipGetLastError());
+            pend_count = 0;
+        }
+        return EKF_OK;
+    }
+
+    // one landmark correction, eager (gain + covariance stream) or delayed (gain only, factors appended).
+    // active_N > 0: the correction is exactly confined to the leading active_N block (data_association()).
+    ekf_status correct(const ekf::CmdSrc& src, int active_N = 0) {
+        if (pend_cap > 0 && src.mode != ekf::SRC_ASSOC) {
+            if (pend_count + 2 > pend_cap) EKFC(flush());
+            ekf::launch_gain_delayed(pv, src, pending(), state_alt, stream);
+            std::swap(pv.state, state_alt);
+            pend_count += 2;
+            return EKF_OK;
+        }
+        EKFC(flush());
+        ekf::PoolView view = pv;
+        if (active_N > 0 && active_N < pv.N) view.N = active_N;
+        if (fused_ok()) {  // single filter: gain + state + covariance in one launch, out of place
+            EKFC(ensure_alt());
+            ekf::launch_correct_fused(view, src, sigma_alt, state_fz, stream);
+            std::swap(pv.sigma, sigma_alt);
+            std::swap(pv.state, state_fz);
+            return EKF_OK;
+        }
+        alt_synced = false;
+        ekf::launch_gain(view, src, stream);
+        if (active_set && active_N == 0) ekf::launch_rank2_active(pv, tuning, touched_bound, stream);
+        else ekf::launch_rank2(view, tuning, stream);
+        return EKF_OK;
+    }
+
+    // single filter: landmark lm is about to be corrected
+    void note_touched(int lm) {
+        if (host_touched.size() != (size_t)pv.n) host_touched.assign(pv.n, 0);
+        if (lm >= 0 && lm < pv.n && !host_touched[lm]) { host_touched[lm] = 1; touched_bound++; }
+        if (touched_bound > pv.n) touched_bound = pv.n;
+    }
+
+    // batch: bound of the touched-set size after every step of a known-association log
+    void compute_log_touch_bound(const int* lm_idx, int T, int vmax) {
+        const int B = pv.B, n = pv.n;
+        std::vector<unsigned char> seen((size_t)B * (n > 0 ? n : 1), 0);
+        std::vector<int> cnt(B, 0);
+        log_touch_bound.assign(T, 0);
+        touch_bound_base = touched_bound;  // |old set UNION new landmarks| <= old bound + new count
+        int best = 0;
+        for (int t = 0; t < T; t++) {
+            for (int b = 0; b < B; b++)
+                for (int v = 0; v < vmax; v++) {
+                    const int lm = lm_idx[((size_t)t * B + b) * vmax + v];
+                    if (lm < 0 || lm >= n) continue;
+                    unsigned char& sflag = seen[(size_t)b * n + lm];
+                    if (!sflag) { sflag = 1; if (++cnt[b] > best) best = cnt[b]; }
+                }
+            log_touch_bound[t] = best;
+        }
+    }
+
+    ekf_status use() {
+        HIPC(hipSetDevice(device));
+        return EKF_OK;
+    }
+
+    template <class Tp>
+    ekf_status dalloc(Tp** p, size_t count) {
+        HIPC(hipMalloc((void**)p, count * sizeof(Tp)));
+        dev_bytes += count * sizeof(Tp);
+        return EKF_OK;
+    }
+
+    ekf_status create(int B, int n, const ekf_params* params, int dev) {
+        if (B <= 0 || n < 0) return fail(EKF_ERR_INVALID, "B must be > 0 and n >= 0");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return fail(EKF_ERR_NO_DEVICE, "no HIP device visible: libekfslam_hip has no CPU path");
+        if (dev < 0) HIPC(hipGetDevice(&dev));
+        if (dev >= count) return fail(EKF_ERR_INVALID, "device index out of range");
+        hipDeviceProp_t prop;
+        HIPC(hipGetDeviceProperties(&prop, dev));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(EKF_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+        device = dev;
+        EKFC(use());
+        HIPC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        ekf_params p;
+        ekf_default_params(&p);
+        if (params) p = *params;
+        pv.p = ekf::Params{p.sigma0_landmark, p.q_pose, p.r_meas, p.gate_new, p.gate_update, p.straight_eps};
+        pv.n = n;
+        pv.N = 3 + 2 * n;
+        pv.ld = round_up(pv.N, 16);
+        pv.B = B;
+        pv.sigma_stride = (size_t)pv.N * pv.ld;
+        EKFC(dalloc(&pv.sigma, (size_t)B * pv.sigma_stride));
+        EKFC(dalloc(&pv.state, (size_t)B * pv.ld));
+        EKFC(dalloc(&pv.Kg, (size_t)B * 2 * pv.ld));
+        EKFC(dalloc(&pv.Gh, (size_t)B * 2 * pv.ld));
+        EKFC(dalloc(&pv.snap, (size_t)B * 4));
+        EKFC(dalloc(&pv.rec, (size_t)B));
+        EKFC(dalloc(&pv.assoc, (size_t)B));
+        EKFC(dalloc(&pv.touch_flag, (size_t)B * (n > 0 ? n : 1)));
+        EKFC(dalloc(&pv.touch_list, (size_t)B * (n > 0 ? n : 1)));
+        EKFC(dalloc(&pv.touch_count, (size_t)B));
+        EKFC(dalloc(&scores, (size_t)B * (n > 0 ? n : 1)));
+        EKFC(dalloc(&digest_dev, (size_t)B * 4));
+        EKFC(dalloc(&poses_dev, (size_t)B * 3));
+        HIPC(hipEventCreate(&ev_begin));
+        HIPC(hipEventCreate(&ev_end));
+        return reset();
+    }
+
+    ekf_status reset() {
+        EKFC(use());
+        pend_count = 0;  // pending factors of the old run are dropped with it
+        touched_hwm = 0;
+        touched_bound = 0;
+        touch_bound_base = 0;
+        std::fill(host_touched.begin(), host_touched.end(), 0);
+        ekf::launch_init(pv, stream);
+        HIPC(hipGetLastError());
+        init_flag = 0;
+        alt_synced = false;
+        return EKF_OK;
+    }
+
+    void destroy() {
+        if (device >= 0) (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, pv.touch_flag, pv.touch_list,
+                        pv.touch_count, scores, meas_dev,
+                        assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
+                        Uf, Vf, state_alt, sigma_alt, state_fz, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        stage_in.release();
+        stage_out.release();
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_end) (void)hipEventDestroy(ev_end);
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+
+    ekf_status sync() {
+        EKFC(use());
+        HIPC(hipStreamSynchronize(stream));
+        return EKF_OK;
+    }
+
+    // host -> device through the pinned staging buffer, ordered on the stream
+    ekf_status upload(void* dst, const void* src, size_t bytes) { return upload2(dst, src, bytes, nullptr, 0); }
+
+    // one H2D copy of two host pieces laid out back to back (piece 2 lands at dst + bytes1)
+    ekf_status upload2(void* dst, const void* src1, size_t bytes1, const void* src2, size_t bytes2) {
+        if (bytes1 + bytes2 == 0) return EKF_OK;
+        Staging& sg = stage_in.acquire();
+        EKFC(sg.reserve(bytes1 + bytes2));
+        EKFC(sg.wait());
+        std::memcpy(sg.host, src1, bytes1);
+        if (bytes2) std::memcpy(static_cast<char*>(sg.host) + bytes1, src2, bytes2);
+        HIPC(hipMemcpyAsync(dst, sg.host, bytes1 + bytes2, hipMemcpyHostToDevice, stream));
+        return sg.mark(stream);
+    }
+
+    // device -> host, blocking
+    ekf_status download(void* dst, const void* src, size_t bytes) {
+        if (bytes == 0) return EKF_OK;
+        EKFC(stage_out.reserve(bytes));
+        HIPC(hipMemcpyAsync(stage_out.host, src, bytes, hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        std::memcpy(dst, stage_out.host, bytes);
+        return EKF_OK;
+    }
+
+    ekf_status get_state(int b, double* out) {
+        if (!out || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "get_state: bad argument");
+        EKFC(use());
+        return download(out, pv.state + (size_t)b * pv.ld, sizeof(double) * pv.N);
+    }
+
+    ekf_status set_state(int b, const double* in) {
+        if (!in || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "set_state: bad argument");
+        EKFC(use());
+        return upload(pv.state + (size_t)b * pv.ld, in, sizeof(double) * pv.N);
+    }
+
+    ekf_status get_cov(int b, double* out) {
+        if (!out || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "get_cov: bad argument");
+        EKFC(use());
+        EKFC(flush());
+        const size_t w = sizeof(double) * pv.N;
+        EKFC(stage_out.reserve(w * pv.N));
+        HIPC(hipMemcpy2DAsync(stage_out.host, w, pv.sigma + (size_t)b * pv.sigma_stride, sizeof(double) * pv.ld, w,
+                              pv.N, hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        std::memcpy(out, stage_out.host, w * pv.N);
+        return EKF_OK;
+    }
+
+    ekf_status set_cov(int b, const double* in) {
+        if (!in || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "set_cov: bad argument");
+        EKFC(use());
+        EKFC(flush());
+        alt_synced = false;
+        touched_hwm = pv.n;  // caller-supplied covariance: no structure may be assumed any more
+        touched_bound = pv.n;
+        std::fill(host_touched.begin(), host_touched.end(), 1);
+        ekf::launch_touch_all(pv, stream);
+        const size_t w = sizeof(double) * pv.N;
+        Staging& sg = stage_in.acquire();
+        EKFC(sg.reserve(w * pv.N));
+        EKFC(sg.wait());
+        std::memcpy(sg.host, in, w * pv.N);
+        HIPC(hipMemcpy2DAsync(pv.sigma + (size_t)b * pv.sigma_stride, sizeof(double) * pv.ld, sg.host, w, w,
+                              pv.N, hipMemcpyHostToDevice, stream));
+        return sg.mark(stream);
+    }
+
+    ekf_status ensure_meas_capacity(int J) {
+        if (J <= jcap) return EKF_OK;
+        HIPC(hipStreamSynchronize(stream));
+        if (meas_dev) HIPC(hipFree(meas_dev));
+        if (assoc_out_dev) HIPC(hipFree(assoc_out_dev));
+        meas_dev = nullptr; assoc_out_dev = nullptr;
+        const int cap = J < 64 ? 64 : round_up(J, 64);
+        EKFC(dalloc(&meas_dev, (size_t)cap * 2));
+        EKFC(dalloc(&assoc_out_dev, (size_t)cap));
+        jcap = cap;
+        return EKF_OK;
+    }
+
+    hipEvent_t* events(size_t need) {
+        while (ev_pool.size() < need) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ev_pool.push_back(e);
+        }
+        return ev_pool.data();
+    }
+};
+
+inline ekf_status checked_launch() {
+    HIPC(hipGetLastError());
+    return EKF_OK;
+}
+
+inline ekf_status free_log(Pool& P) {
+    HIPC(hipStreamSynchronize(P.stream));
+    for (void* p : {(void*)P.log_twist, (void*)P.log_lm, (void*)P.log_z, (void*)P.log_init, (void*)P.log_truth})
+        if (p) HIPC(hipFree(p));
+    P.log_twist = nullptr; P.log_lm = nullptr; P.log_z = nullptr; P.log_init = nullptr; P.log_truth = nullptr;
+    P.T = 0; P.vmax = 0; P.log_bytes = 0;
+    return EKF_OK;
+}
+
+inline ekf_status free_ulog(Pool& P) {
+    HIPC(hipStreamSynchronize(P.stream));
+    for (void* p : {(void*)P.ulog_twist, (void*)P.ulog_count, (void*)P.ulog_meas, (void*)P.ulog_assoc, (void*)P.ulog_truth})
+        if (p) HIPC(hipFree(p));
+    P.ulog_twist = nullptr; P.ulog_count = nullptr; P.ulog_meas = nullptr; P.ulog_assoc = nullptr; P.ulog_truth = nullptr;
+    P.truth_is_unknown_log = 0;
+    P.uT = 0; P.ujmax = 0; P.ulog_bytes = 0;
+    P.ucount_host.clear();
+    return EKF_OK;
+}
+
+}  // namespace ekfrt
+
+struct ekf_filter_s { ekfrt::Pool pool; };
+struct ekf_batch_s { ekfrt::Pool pool; };
