@@ -182,3 +182,39 @@ def test_batch_unknown_outgrows_the_small_path(hip, oracle):
     o, known, d = _oracle_replay(oracle, log, 0, n, 0, T)
     assert np.array_equal(snap[0][0][:, 0], d)
     assert_parity(snap[0][2][0], snap[0][3][0], o.state, o.cov, FP64_TOL, "outgrowing the small path")
+
+
+@pytest.mark.parametrize("n", [30, 70])   # LDS-resident paths / multi-kernel paths
+def test_batch_unknown_then_known_then_unknown(hip, oracle, n):
+    """The two node loops on the same pool: after a known-association run (which corrects arbitrary indices and, on its
+    first call, re-initialises every landmark, ekf_slam.cpp:113-128) the discovered-prefix shortcut must be off, and the
+    device-resident known counts must still carry over."""
+    B, T = 3, 36
+    ulog = _ragged_log(n, B, T, 2468, 5)
+    kcfg = synth.SimConfig(n=n, steps=T, filters=B, seed=2468, half_extent=1.5, min_spacing=0.25, max_visible_dis=0.7, vmax=6)
+    klog = synth.make_known_log(kcfg)
+    klog.lm_idx[12] = -1   # step 12 is this pool's FIRST measurement() call: landmark initialisation only
+    bt = hip.BatchEKF(B, n)
+    bt.upload_unknown_log(ulog.twist, ulog.count, ulog.meas_xy)
+    bt.upload_known_log(klog.twist, klog.lm_idx, klog.z_xy, klog.init_xy)
+    bt.run_unknown(0, 12)
+    bt.run_known(12, 24)
+    bt.run_unknown(24, T)
+    dec = bt.decisions()
+    for b in range(B):
+        o, known = oracle.OracleEKF(n, oracle.DENSE), np.zeros(n, dtype=np.uint8)
+        for t in range(T):
+            if 12 <= t < 24:
+                o.prediction(*klog.twist[t, b])
+                sensor, vis = klog.expand_step(t, b)
+                if t == 12:   # the first measurement() call of this object: the log's init vector, nothing visible
+                    sensor, vis = klog.init_xy[b].copy(), np.zeros(n, dtype=np.uint8)
+                o.measurement(sensor, vis)
+            else:
+                J = int(ulog.count[t, b])
+                o.prediction(*ulog.twist[t, b])
+                a = o.data_association(ulog.meas_xy[t, b, :J], known)
+                assert np.array_equal(dec[t, b, :J], a), f"filter {b} step {t}"
+        assert bt.known_counts()[b] == int(known.sum())
+        assert_parity(bt.state(b), bt.cov(b), o.state, o.cov, FP64_TOL, f"mixed loops, filter {b}")
+    bt.close()

@@ -12,18 +12,25 @@ pytestmark = pytest.mark.gpu
 
 def _scenario(hip, oracle, seed):
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(1, 61))
+    n = int(rng.integers(1, 91))
     f, o = hip.EKF_SLAM(n), oracle.OracleEKF(n, oracle.DENSE)
     mode = int(rng.choice([0, 0, 3, 16]))
     f.set_update_mode(mode, symmetric_gather=False)
     f.set_small_map_path(bool(rng.integers(0, 2)))
     f.set_active_prefix(bool(rng.integers(0, 2)))
+    f.set_fused_correction(bool(rng.integers(0, 2)))
     world = rng.uniform(-2.5, 2.5, size=(n, 2))
     world[np.hypot(world[:, 0], world[:, 1]) < 0.3] += 0.6          # keep landmarks off the start pose
     pose = np.zeros(3)                                              # true (theta, x, y)
     known_f, known_o = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
-    use_assoc = rng.random() < 0.4
+    assoc_p = float(rng.choice([0.0, 0.0, 0.5, 1.0]))   # share of steps that go through data_association()
     for t in range(int(rng.integers(6, 22))):
+        if rng.random() < 0.1:                          # live switches must not disturb the filter
+            f.set_fused_correction(bool(rng.integers(0, 2)))
+        if rng.random() < 0.05:
+            mode = int(rng.choice([0, 3, 16]))
+            f.set_update_mode(mode, symmetric_gather=False)
+        use_assoc = rng.random() < assoc_p
         dth = float(rng.choice([0.0, 5e-7, rng.normal(0, 0.3), rng.normal(0, 1.5)]))   # both branches of :79
         dx = float(rng.normal(0.05, 0.05))
         pose[1] += dx * np.cos(pose[0]); pose[2] += dx * np.sin(pose[0]); pose[0] += dth
