@@ -105,9 +105,11 @@ ekf_status ekf_set_init_flag(ekf_handle h, int flag);
  * bit-identical to enable == 0 for finite states. */
 ekf_status ekf_set_active_prefix(ekf_handle h, int enable);
 ekf_status ekf_batch_set_active_prefix(ekf_batch_handle hb, int enable);
-/* ekf_batch_run_unknown: while every filter's discovered prefix fits the LDS-resident small-map path
- * (3 + 2*(known_count + readings of the step) <= 104), one launch per step handles the whole pool
- * (enable != 0, default).  enable == 0: always four launches per measurement slot.  Bit-identical. */
+/* LDS-resident forms of the batch runs (enable != 0, default; bit-identical to the multi-kernel replay):
+ *   ekf_batch_run_known   N = 3 + 2n <= 104 (e.g. the reference's n = 20) and vmax <= 64: the WHOLE step range is
+ *                         one launch, every filter's covariance staying in LDS from the first step to the last;
+ *   ekf_batch_run_unknown while every filter's discovered prefix fits (3 + 2*(known_count + readings of the
+ *                         step) <= 104): one launch per step instead of four launches per measurement slot. */
 ekf_status ekf_batch_set_small_map_path(ekf_batch_handle hb, int enable);
 /* Single filter, maps beyond the small-map path: every eager correction (gain K, state, covariance) runs as
  * ONE launch that writes Sigma - K(H Sigma) out of place into a second buffer; the two buffers swap after
