@@ -135,11 +135,19 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
                 p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
             }
         }
+        // the factor rows of pairs j+2 and j+4 are in flight while pair j is folded in (trips past the end
+        // re-read pair 0): this loop streams count x 32 B per lane and is bandwidth-bound
+        auto ld4 = [&](int j, double2_t& a0, double2_t& a1, double2_t& b0, double2_t& b1) {
+            a0 = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
+            a1 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
+            b0 = *reinterpret_cast<const double2_t*>(Vb + (size_t)j * ld + r);
+            b1 = *reinterpret_cast<const double2_t*>(Vb + (size_t)(j + 1) * ld + r);
+        };
+        double2_t ua = zero2, ub = zero2, va = zero2, vb = zero2, ua1 = zero2, ub1 = zero2, va1 = zero2, vb1 = zero2;
+        if (rc > 0) { ld4(0, ua, ub, va, vb); ld4(2 < rc ? 2 : 0, ua1, ub1, va1, vb1); }
         for (int j = 0; j < rc; j += 2) {
-            const double2_t ua = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
-            const double2_t ub = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
-            const double2_t va = *reinterpret_cast<const double2_t*>(Vb + (size_t)j * ld + r);
-            const double2_t vb = *reinterpret_cast<const double2_t*>(Vb + (size_t)(j + 1) * ld + r);
+            double2_t ua2, ub2, va2, vb2;
+            ld4(j + 4 < rc ? j + 4 : 0, ua2, ub2, va2, vb2);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 const double v5a = sh_V5[k * kMaxPending + j], v5b = sh_V5[k * kMaxPending + j + 1];
@@ -149,6 +157,8 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
                 g[k].x = __builtin_fma(-u5b, vb.x, __builtin_fma(-u5a, va.x, g[k].x));
                 g[k].y = __builtin_fma(-u5b, vb.y, __builtin_fma(-u5a, va.y, g[k].y));
             }
+            ua = ua1; ub = ub1; va = va1; vb = vb1;
+            ua1 = ua2; ub1 = ub2; va1 = va2; vb1 = vb2;
         }
         double2_t sht0 = zero2, sht1 = zero2;
 #pragma unroll
