@@ -15,7 +15,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libekfslam_hip.so")
+LIB_PATH = os.environ.get("EKF_LIB_PATH", os.path.join(_HERE, "libekfslam_hip.so"))  # (override: A/B of two builds)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

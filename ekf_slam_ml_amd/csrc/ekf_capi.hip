@@ -132,6 +132,21 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     return checked_launch();
 }
 
+// Tail of every data_association() form: one synchronising read-back of the association record and the
+// decisions, then the caller's known_list (:323) and the host-side bounds are brought up to date.
+static ekf_status associate_finish(Pool& P, int known_count, int J, uint8_t* known, int* assoc_out) {
+    const int n = P.pv.n;
+    ekf::AssocRec rec;
+    EKFC(P.download2(&rec, P.pv.assoc, sizeof(rec), assoc_out, P.assoc_out_dev, assoc_out ? sizeof(int) * J : 0));
+    for (int i = known_count; i < rec.known_count && i < n; i++) known[i] = 1;  // :323
+    P.dev_known_count = rec.known_count;
+    if (rec.known_count > P.touched_hwm) P.touched_hwm = rec.known_count < n ? rec.known_count : n;
+    // for the host-side bound every landmark below the new known_count counts as touched (a superset
+    // of what this call's decisions actually corrected)
+    for (int i = 0; i < rec.known_count && i < n; i++) P.note_touched(i);
+    return EKF_OK;
+}
+
 ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* known, int* assoc_out) {
     if (!h || !known || J < 0 || (J > 0 && !meas_xy)) return fail(EKF_ERR_INVALID, "ekf_associate: bad argument");
     Pool& P = h->pool;
@@ -150,15 +165,26 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         P.alt_synced = false;
         ekf::launch_small_associate(P.pv, P.meas_dev, J, known_count, P.assoc_out_dev, P.stream);
         EKFC(checked_launch());
-        ekf::AssocRec rec_s;
-        EKFC(P.download(&rec_s, P.pv.assoc, sizeof(rec_s)));
-        for (int i = known_count; i < rec_s.known_count && i < n; i++) known[i] = 1;  // :323
-        if (rec_s.known_count > P.touched_hwm) P.touched_hwm = rec_s.known_count < n ? rec_s.known_count : n;
-        for (int i = 0; i < rec_s.known_count && i < n; i++) P.note_touched(i);
-        if (assoc_out) EKFC(P.download(assoc_out, P.assoc_out_dev, sizeof(int) * J));
-        return EKF_OK;
+        return associate_finish(P, known_count, J, known, assoc_out);
     }
-    ekf::launch_assoc_begin(P.pv, nullptr, known_count, P.stream);
+    // known_count lives on the device between calls (the node only ever passes back the list this function
+    // returned); it is rewritten only when the caller's list says something else
+    if (known_count != P.dev_known_count) ekf::launch_assoc_begin(P.pv, nullptr, known_count, P.stream);
+    {   // A big map whose DISCOVERED part is still small: the whole call as one LDS-resident launch on the prefix
+        // (everything beyond 3 + 2*(known_count + J), and beyond what this object ever corrected, still holds
+        // constructor values).
+        int m = known_count + J < n ? known_count + J : n;
+        if (P.touched_hwm > m) m = P.touched_hwm;
+        const int Nb = 3 + 2 * m;
+        if (P.small_path && P.active_prefix && n > 0 && Nb <= ekf::small_max_dim()) {
+            P.alt_synced = false;
+            ekf::PoolView pva = P.pv;
+            pva.N = Nb;
+            ekf::launch_pool_associate(pva, P.meas_dev, nullptr, J, 3 + 2 * P.touched_hwm, P.assoc_out_dev, nullptr, P.stream);
+            EKFC(checked_launch());
+            return associate_finish(P, known_count, J, known, assoc_out);
+        }
+    }
     ekf::CmdSrc src{};
     src.mode = ekf::SRC_ASSOC;
     src.assoc = P.pv.assoc;
@@ -184,15 +210,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         EKFC(P.correct(src, active_N));                                                   // :331-390
     }
     EKFC(checked_launch());
-    ekf::AssocRec rec;
-    EKFC(P.download(&rec, P.pv.assoc, sizeof(rec)));
-    for (int i = known_count; i < rec.known_count && i < n; i++) known[i] = 1;  // :323
-    if (rec.known_count > P.touched_hwm) P.touched_hwm = rec.known_count < n ? rec.known_count : n;
-    // for the host-side bound every landmark below the new known_count counts as touched (a superset
-    // of what this call's decisions actually corrected)
-    for (int i = 0; i < rec.known_count && i < n; i++) P.note_touched(i);
-    if (assoc_out) EKFC(P.download(assoc_out, P.assoc_out_dev, sizeof(int) * J));
-    return EKF_OK;
+    return associate_finish(P, known_count, J, known, assoc_out);
 }
 
 ekf_status ekf_maha_scores(ekf_handle h, double meas_x, double meas_y, int M, double* scores_out) {

@@ -266,6 +266,7 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     EKFC(P.use());
     EKFC(P.flush());
     P.alt_synced = false;
+    P.dev_known_count = -1;
     const int B = P.pv.B, n = P.pv.n, jmax = P.ujmax;
     size_t launches = 0;
     for (int t = t_begin; t < t_end; t++) {

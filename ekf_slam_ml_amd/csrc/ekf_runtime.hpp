@@ -140,6 +140,7 @@ struct Pool {
     int pend_cap = 0, pend_count = 0;
     int pend_symmetric = 0;
     int active_prefix = 1;  // data_association(): restrict corrections to the discovered prefix of the state
+    int dev_known_count = -1;  // single filter: AssocRec.known_count as last left on the device (-1 = unknown)
     int touched_hwm = 0;    // landmarks [0, touched_hwm) may carry non-constructor covariance (single filter)
     int small_path = 1;     // measurement() of a small map runs as one LDS-resident launch (ekf_small.hip)
     int active_set = 0;     // eager corrections stream only the rows of the touched set (opt-in)
@@ -323,6 +324,7 @@ struct Pool {
         HIPC(hipGetLastError());
         init_flag = 0;
         alt_synced = false;
+        dev_known_count = 0;  // k_init resets the association record
         return EKF_OK;
     }
 
@@ -372,6 +374,19 @@ struct Pool {
         HIPC(hipMemcpyAsync(stage_out.host, src, bytes, hipMemcpyDeviceToHost, stream));
         HIPC(hipStreamSynchronize(stream));
         std::memcpy(dst, stage_out.host, bytes);
+        return EKF_OK;
+    }
+
+    // two device -> host pieces, ONE stream synchronisation (piece 2 may be empty)
+    ekf_status download2(void* dst1, const void* src1, size_t bytes1, void* dst2, const void* src2, size_t bytes2) {
+        const size_t off2 = (bytes1 + 63) / 64 * 64;
+        EKFC(stage_out.reserve(off2 + bytes2));
+        char* hostp = static_cast<char*>(stage_out.host);
+        HIPC(hipMemcpyAsync(hostp, src1, bytes1, hipMemcpyDeviceToHost, stream));
+        if (bytes2) HIPC(hipMemcpyAsync(hostp + off2, src2, bytes2, hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        std::memcpy(dst1, hostp, bytes1);
+        if (bytes2) std::memcpy(dst2, hostp + off2, bytes2);
         return EKF_OK;
     }
 

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(THREADS) void k_pool_associate(PoolView pv, const d
                                                             unsigned long long* __restrict__ corr_counter) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x;
-    const int J = count[b];
+    const int J = count ? count[b] : jmax;  // count == nullptr: every filter has exactly jmax readings
     if (J <= 0) return;  // uniform
     const int kc = pv.assoc[b].known_count;
     int m = kc + J < pv.n ? kc + J : pv.n;
