@@ -202,6 +202,19 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
             if (P.touched_hwm > m) m = P.touched_hwm;
             active_N = 3 + 2 * m;
         }
+        if (P.fused_ok()) {  // two launches per measurement: scores (+ correction terms), then decision + correction
+            EKFC(P.ensure_alt());
+            const ekf::MeasSrc msf{mj, 2, nullptr, 0, P.terms};
+            ekf::launch_maha(P.pv, msf, P.scores, -1, known_count + j < n ? known_count + j : n, P.stream);
+            ekf::PoolView view = P.pv;
+            if (active_N > 0 && active_N < P.pv.N) view.N = active_N;
+            ekf::launch_associate_fused(view, msf, P.scores, P.assoc_alt, P.assoc_out_dev + j, P.sigma_alt, P.state_fz,
+                                        P.stream);
+            std::swap(P.pv.sigma, P.sigma_alt);
+            std::swap(P.pv.state, P.state_fz);
+            std::swap(P.pv.assoc, P.assoc_alt);
+            continue;
+        }
         const ekf::MeasSrc ms{mj, 2, nullptr, 0};
         ekf::launch_maha(P.pv, ms, P.scores, -1, known_count + j < n ? known_count + j : n, P.stream);  // :300-309
         ekf::launch_assoc_decide(P.pv, ms, P.scores, P.assoc_out_dev, 0, j, nullptr, P.stream);    // :293-330

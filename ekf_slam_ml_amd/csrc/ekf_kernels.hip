@@ -570,7 +570,16 @@ __global__ __launch_bounds__(256) void k_maha(PoolView pv, MeasSrc ms, double* s
     const double v0 = m.z0 - m.zh0, v1 = m.z1 - m.zh1;
     const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
     const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
-    if (lane == 0) scores[(size_t)b * pv.n + i] = t0 * v0 + t1 * v1;
+    if (lane == 0) {
+        scores[(size_t)b * pv.n + i] = t0 * v0 + t1 * v1;
+        if (ms.terms) {  // what the correction of landmark i would need (same pose, same Sigma: :331-381)
+            double* tr = ms.terms + ((size_t)b * pv.n + i) * 16;
+#pragma unroll
+            for (int k = 0; k < 5; k++) { tr[k] = m.H[0][k]; tr[5 + k] = m.H[1][k]; }
+            tr[10] = Si[0][0]; tr[11] = Si[0][1]; tr[12] = Si[1][0]; tr[13] = Si[1][1];
+            tr[14] = v0; tr[15] = v1;
+        }
+    }
 }
 
 __global__ void k_assoc_begin(PoolView pv, const int* known_count_dev, int known_count_imm) {

@@ -87,6 +87,8 @@ struct MeasSrc {
     int stride;
     const int* count;   // nullable: filter b takes part in slot j iff j < count[b]
     int j;
+    double* terms;      // nullable, single filter: k_maha keeps {H[2][5], S^-1[2][2], nu0, nu1 (unwrapped)} of every
+                        // scored landmark here ([n][16]) so that the correction of the winner need not rebuild them
 };
 
 struct PoolView {
@@ -207,6 +209,10 @@ void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s);
 void launch_rank2_active(const PoolView& pv, const Rank2Tuning& t, int max_touched, hipStream_t s);
 void launch_touch_all(const PoolView& pv, hipStream_t s);  // marks every landmark touched (after set_cov)
 // data_association(): scores for landmarks [0, known_count) of every filter, one landmark per wavefront
+// data_association() of ONE measurement after its scores: gate decision, landmark initialisation and the whole
+// correction in one launch, out of place (ekf_fused.hip).  Reads pv.assoc (known_count), writes assoc_next.
+void launch_associate_fused(const PoolView& pv, const MeasSrc& ms, const double* scores, AssocRec* assoc_next,
+                            int* assoc_out_j, double* sigma_next, double* state_next, hipStream_t s);
 // gain + state + covariance of one correction in one launch, OUT OF PLACE into (sigma_next, state_next)
 // (ekf_fused.hip); the caller swaps the buffers afterwards
 void launch_correct_fused(const PoolView& pv, const CmdSrc& src, double* sigma_next, double* state_next, hipStream_t s);

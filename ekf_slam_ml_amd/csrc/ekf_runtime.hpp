@@ -155,12 +155,16 @@ struct Pool {
     double* sigma_alt = nullptr;
     double* state_fz = nullptr;
     bool alt_synced = false;  // sigma_alt equals sigma outside the region the next fused correction rewrites
+    ekf::AssocRec* assoc_alt = nullptr;  // "next" association record of the fused data_association() step
+    double* terms = nullptr;             // [n][16] correction terms k_maha leaves for the winner
 
     bool fused_ok() const { return fused && pv.B == 1 && pend_cap == 0 && !active_set; }
     ekf_status ensure_alt() {
         if (!sigma_alt) {
             EKFC(dalloc(&sigma_alt, (size_t)pv.B * pv.sigma_stride));
             EKFC(dalloc(&state_fz, (size_t)pv.B * pv.ld));
+            EKFC(dalloc(&assoc_alt, (size_t)pv.B));
+            EKFC(dalloc(&terms, (size_t)pv.B * (pv.n > 0 ? pv.n : 1) * 16));
             alt_synced = false;
         }
         if (!alt_synced) {
@@ -334,7 +338,7 @@ struct Pool {
         void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, pv.touch_flag, pv.touch_list,
                         pv.touch_count, scores, meas_dev,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
-                        Uf, Vf, state_alt, sigma_alt, state_fz, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter};
+                        Uf, Vf, state_alt, sigma_alt, state_fz, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();
