@@ -10,6 +10,8 @@
 // LDS rows use an odd stride so that the column gather Sigma(r, c5) is bank-conflict-free.
 #include "ekf_kernels.hpp"
 
+#include <climits>
+
 namespace ekf {
 
 constexpr int kSmallThreads = 256;
@@ -121,8 +123,7 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
     double* st = S + (size_t)N * ldS;
     double* Gg = st + N;
     __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
-    __shared__ double sh_score[128];
-    __shared__ int sh_M, sh_lm, sh_applied;
+    __shared__ int sh_M, sh_lm, sh_new, sh_applied;
 
     double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
     double* stg = pv.state + (size_t)b * ld;
@@ -135,30 +136,41 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
     for (int j = 0; j < J; j++) {                       // :291 sequential, state-carrying
         const double mx = meas[2 * j], my = meas[2 * j + 1];
         const int M = sh_M;
-        for (int i = tid; i < M; i += THREADS) {          // :300-309, one landmark per LANE, all from LDS
-            MeasTerms m;                                 // fresh pose per score, :219-221
-            measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, st[0], st[1], st[2], m);
-            double S55[5][5], Sm[2][2], Si[2][2];
+        // :300-309, one landmark per LANE (M <= 50 < 64: wave 0 holds them all), everything from LDS.  The lane
+        // keeps H, S^-1 and nu of its landmark: if it wins, they are exactly what the correction needs.
+        MeasTerms m;
+        double Si[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        double v0 = 0.0, v1 = 0.0;
+        double d = pv.p.gate_new;                        // :293
+        int di = INT_MAX;
+        if (tid < M) {
+            const int i = tid;
+            measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, st[0], st[1], st[2], m);  // fresh pose, :219-221
+            double S55[5][5], Sm[2][2];
 #pragma unroll
             for (int k = 0; k < 5; k++)
 #pragma unroll
                 for (int l = 0; l < 5; l++) S55[k][l] = S[idx5(k, i) * ldS + idx5(l, i)];
             innovation_cov(S55, m.H, pv.p.r_meas, Sm);   // same summation order as k_maha's shuffle folds
             inv2(Sm, Si);
-            const double v0 = m.z0 - m.zh0, v1 = m.z1 - m.zh1;   // bearing NOT wrapped, :269
+            v0 = m.z0 - m.zh0; v1 = m.z1 - m.zh1;        // bearing NOT wrapped, :269
             const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
             const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
-            sh_score[i] = t0 * v0 + t1 * v1;
+            const double sc = t0 * v0 + t1 * v1;
+            if (sc < d) { d = sc; di = i; }              // :305-309 (NaN never wins)
         }
-        __syncthreads();
-        if (tid == 0) {                                  // :293-330
-            double best = pv.p.gate_new;
-            int idx = M;
-            for (int i = 0; i < M; i++) {
-                const double d = sh_score[i];
-                if (d < best) { best = d; idx = i; }
+        if (tid < kWave) {  // sequential-scan semantics = lexicographic (d, i) minimum, as in k_assoc_decide
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = __shfl_down(d, off, kWave);
+                const int oi = __shfl_down(di, off, kWave);
+                if (od < d || (od == d && oi < di)) { d = od; di = oi; }
             }
-            int Mn = M;
+        }
+        if (tid == 0) {                                  // :293-330
+            double best = d;
+            const int idx = (di == INT_MAX) ? M : di;
+            int Mn = M, is_new = 0;
             if (idx == M && idx < n) {                   // :318-327 new landmark
                 const double theta = st[0], x = st[1], y = st[2];
                 const double ri = sqrt(mx * mx + my * my);
@@ -167,31 +179,41 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
                 st[2 * idx + 3 + 1] = y + ri * sin(phii + theta);
                 Mn = M + 1;
                 best = 0.0;
+                is_new = 1;
             }
             const int active = (best < pv.p.gate_update) && idx < n;
             sh_M = Mn;
             sh_lm = active ? idx : -1;
+            sh_new = is_new;
             assoc_out[j] = sh_lm;
-            if (active) sh_applied++;
-            if (active) {                                // :331-381 with the FRESH pose
-                MeasTerms m;
-                measurement_terms(st[2 * idx + 3], st[2 * idx + 4], mx, my, st[0], st[1], st[2], m);
-                double S55[5][5], Sm[2][2], Si[2][2];
-                for (int k = 0; k < 5; k++)
-                    for (int l = 0; l < 5; l++) S55[k][l] = S[idx5(k, idx) * ldS + idx5(l, idx)];
-                innovation_cov(S55, m.H, pv.p.r_meas, Sm);
-                inv2(Sm, Si);
-                for (int a = 0; a < 2; a++)
-                    for (int k = 0; k < 5; k++) sh_H[a * 5 + k] = m.H[a][k];
-                sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
-                sh_nu[0] = m.z0 - m.zh0;
-                sh_nu[1] = normalize_angle(m.z1 - m.zh1);
-                touch_landmark(pv, b, idx);
-            }
+            if (active) { sh_applied++; touch_landmark(pv, b, idx); }
         }
         __syncthreads();
         const int lm = sh_lm;
         if (lm < 0) continue;                            // dropped (uniform)
+        if (sh_new) {                                    // :331-381 with the FRESH pose: a new landmark has no record
+            if (tid == 0) {
+                MeasTerms mn;
+                measurement_terms(st[2 * lm + 3], st[2 * lm + 4], mx, my, st[0], st[1], st[2], mn);
+                double S55[5][5], Sm[2][2], Sn[2][2];
+                for (int k = 0; k < 5; k++)
+                    for (int l = 0; l < 5; l++) S55[k][l] = S[idx5(k, lm) * ldS + idx5(l, lm)];
+                innovation_cov(S55, mn.H, pv.p.r_meas, Sm);
+                inv2(Sm, Sn);
+                for (int a = 0; a < 2; a++)
+                    for (int k = 0; k < 5; k++) sh_H[a * 5 + k] = mn.H[a][k];
+                sh_Si[0] = Sn[0][0]; sh_Si[1] = Sn[0][1]; sh_Si[2] = Sn[1][0]; sh_Si[3] = Sn[1][1];
+                sh_nu[0] = mn.z0 - mn.zh0;
+                sh_nu[1] = normalize_angle(mn.z1 - mn.zh1);
+            }
+        } else if (tid == lm) {                          // the winning lane hands over what it scored with
+            for (int a = 0; a < 2; a++)
+                for (int k = 0; k < 5; k++) sh_H[a * 5 + k] = m.H[a][k];
+            sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
+            sh_nu[0] = v0;
+            sh_nu[1] = normalize_angle(v1);              // :183 (the score used it unwrapped)
+        }
+        __syncthreads();
         double k0 = 0.0, k1 = 0.0;
         const int r = tid;
         if (r < N) {
