@@ -37,7 +37,7 @@ SYMBOLS = [
     "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
     "ekf_set_update_mode", "ekf_batch_set_update_mode",
     "ekf_default_sim_params", "ekf_batch_simulate_known_log", "ekf_batch_download_log", "ekf_batch_mc_stats",
-    "ekf_circle_fit_scans",
+    "ekf_circle_fit_scans", "ekf_normalize_angles",
     "ekf_default_lidar_params", "ekf_batch_simulate_unknown_log", "ekf_batch_download_unknown_log", "ekf_simulate_scans",
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
 ]
@@ -167,6 +167,7 @@ def load():
         "ekf_batch_download_unknown_log": [h, _dp, _ip, _dp, _dp],
         "ekf_simulate_scans": [C.c_int, C.POINTER(SimParams), C.POINTER(LidarParams), _dp, C.c_int, _dp, C.c_int,
                                C.c_int, _dp],
+        "ekf_normalize_angles": [C.c_int, _dp, C.c_int, _dp],
         "ekf_circle_fit_scans": [C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _ip, _dp, _ip],
         "ekf_dense_create": [C.c_int, C.c_int, C.POINTER(h)],
         "ekf_dense_destroy": [h],
@@ -574,6 +575,14 @@ def simulate_scans(poses, world, seed=7, first_filter_id=0, step=0, lidar=None, 
     w = np.ascontiguousarray(world, dtype=np.float64).reshape(-1, 2)
     out = np.empty((len(ps), lp.n_beams))
     _check(lib.ekf_simulate_scans(device, C.byref(sp), C.byref(lp), _d(w), len(w), _d(ps), len(ps), int(step), _d(out)))
+    return out
+
+
+def normalize_angles(values, device=-1):
+    """rigid2d::normalize_angle (rigid2d.cpp:336-345) evaluated by the device helper the kernels use."""
+    v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+    out = np.empty_like(v)
+    _check(load().ekf_normalize_angles(device, _d(v), len(v), _d(out)))
     return out
 
 

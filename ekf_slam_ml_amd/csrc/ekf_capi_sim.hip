@@ -246,6 +246,31 @@ ekf_status ekf_simulate_scans(int device, const ekf_sim_params* sp, const ekf_li
     return st;
 }
 
+ekf_status ekf_normalize_angles(int device, const double* in, int count, double* out) {
+    if (count < 0 || (count > 0 && (!in || !out))) return fail(EKF_ERR_INVALID, "ekf_normalize_angles: bad argument");
+    if (count == 0) return EKF_OK;
+    int devs = 0;
+    if (hipGetDeviceCount(&devs) != hipSuccess || devs <= 0)
+        return fail(EKF_ERR_NO_DEVICE, "no HIP device visible: libekfslam_hip has no CPU path");
+    if (device < 0) HIPC(hipGetDevice(&device));
+    if (device >= devs) return fail(EKF_ERR_INVALID, "device index out of range");
+    HIPC(hipSetDevice(device));
+    double *d_in = nullptr, *d_out = nullptr;
+    auto body = [&]() -> ekf_status {
+        HIPC(hipMalloc((void**)&d_in, sizeof(double) * count));
+        HIPC(hipMalloc((void**)&d_out, sizeof(double) * count));
+        HIPC(hipMemcpy(d_in, in, sizeof(double) * count, hipMemcpyHostToDevice));
+        ekf::launch_normalize_angles(d_in, count, d_out, nullptr);
+        HIPC(hipGetLastError());
+        HIPC(hipMemcpy(out, d_out, sizeof(double) * count, hipMemcpyDeviceToHost));
+        return EKF_OK;
+    };
+    const ekf_status st = body();
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return st;
+}
+
 ekf_status ekf_circle_fit_scans(int device, const double* ranges, int S, int n_beams, int max_out, double* centres,
                                 double* radii, int* counts, double* all_clusters, int* n_clusters) {
     if (!ranges || !centres || !radii || !counts || S < 0 || n_beams < 1 || max_out < 1 ||

@@ -793,6 +793,16 @@ void launch_assoc_decide(const PoolView& pv, const MeasSrc& ms, const double* sc
                        corr_counter);
 }
 
+__global__ void k_normalize_angles(const double* __restrict__ in, int count, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = normalize_angle(in[i]);
+}
+
+void launch_normalize_angles(const double* in, int count, double* out, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_normalize_angles, dim3((count + 255) / 256), dim3(256), 0, s, in, count, out);
+}
+
 void launch_checksum(const PoolView& pv, double* out, hipStream_t s) {
     const int gx = pv.N < 64 ? pv.N : 64;
     hipLaunchKernelGGL(k_checksum, dim3(gx, pv.B), dim3(256), 0, s, pv, out);

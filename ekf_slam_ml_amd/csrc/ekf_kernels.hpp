@@ -122,11 +122,23 @@ __device__ __forceinline__ void touch_landmark(const PoolView& pv, int b, int lm
     }
 }
 
-// rigid2d/src/rigid2d.cpp:336-345 -- double-fmod form, range (-pi, pi]
+// rigid2d/src/rigid2d.cpp:336-345 -- double-fmod form, range (-pi, pi].
+// fmod is exact, so for |rad| < 2*pi (every angle the filter produces in normal operation) the two calls reduce to
+// identities and one exact subtraction: fmod(rad, 2pi) = rad, and s = rad + 2pi lies in [0, 4pi], where
+// fmod(s, 2pi) is s or s - 2pi (exact by Sterbenz's lemma; s = 4pi gives 2pi here and 0 after the final fold,
+// as the reference's 0).  Bit-identical to the two-fmod form for every input (tests/test_gpu_parity.py sweeps it
+// against the reference build); the general form handles |rad| >= 2pi, NaN and infinities.
 __device__ __forceinline__ double normalize_angle(double rad) {
-    double reduced_ang = fmod(rad, (2 * kPI));
-    double ang = fmod((reduced_ang + (2 * kPI)), (2 * kPI));
-    if (ang > kPI) ang = ang - (2 * kPI);
+    const double two_pi = (2 * kPI);
+    double ang;
+    if (fabs(rad) < two_pi) {
+        ang = rad + two_pi;
+        if (ang >= two_pi) ang = ang - two_pi;
+    } else {
+        double reduced_ang = fmod(rad, two_pi);
+        ang = fmod((reduced_ang + two_pi), two_pi);
+    }
+    if (ang > kPI) ang = ang - two_pi;
     return ang;
 }
 
@@ -136,10 +148,17 @@ struct MeasTerms {
     double H[2][5];     // non-zero columns {0,1,2,3+2i,4+2i}    ekf_slam.cpp:158-166
 };
 
+// the predicted half of measurement_terms (everything that depends on the state); m.z0, m.z1 are left alone
+__device__ __forceinline__ void predicted_terms(double tx, double ty, double theta, double x, double y, MeasTerms& m);
+
 __device__ __forceinline__ void measurement_terms(double tx, double ty, double sx, double sy, double theta,
                                                   double x, double y, MeasTerms& m) {
     m.z0 = sqrt(sx * sx + sy * sy);
     m.z1 = atan2(sy, sx);
+    predicted_terms(tx, ty, theta, x, y, m);
+}
+
+__device__ __forceinline__ void predicted_terms(double tx, double ty, double theta, double x, double y, MeasTerms& m) {
     double delta_x = tx - x, delta_y = ty - y;
     double d = delta_x * delta_x + delta_y * delta_y;
     m.zh0 = sqrt(d);
@@ -216,6 +235,8 @@ void launch_associate_fused(const PoolView& pv, const MeasSrc& ms, const double*
 // gain + state + covariance of one correction in one launch, OUT OF PLACE into (sigma_next, state_next)
 // (ekf_fused.hip); the caller swaps the buffers afterwards
 void launch_correct_fused(const PoolView& pv, const CmdSrc& src, double* sigma_next, double* state_next, hipStream_t s);
+// parity hook of normalize_angle (a8): out[i] = normalize_angle(in[i])
+void launch_normalize_angles(const double* in, int count, double* out, hipStream_t s);
 // m_bound >= 0: host-side upper bound of every filter's known_count (sizes the grid)
 void launch_maha(const PoolView& pv, const MeasSrc& ms, double* scores /*[B][n]*/, int m_override, int m_bound,
                  hipStream_t s);

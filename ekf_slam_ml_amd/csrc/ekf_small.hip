@@ -334,7 +334,8 @@ __global__ __launch_bounds__(THREADS) void k_pool_run_known(PoolView pv, const d
 
     for (int t = t0; t < t1; t++) {
         __syncthreads();  // previous step done with sh_lmv / sh_z / sh_tw; first trip: LDS image complete
-        if (tid < vmax) { sh_lmv[tid] = lm_n; sh_z[2 * tid] = zx_n; sh_z[2 * tid + 1] = zy_n; }
+        // (r, phi) of every reading of the step at once, one reading per lane (ekf_slam.cpp:142-146)
+        if (tid < vmax) { sh_lmv[tid] = lm_n; sh_z[2 * tid] = sqrt(zx_n * zx_n + zy_n * zy_n); sh_z[2 * tid + 1] = atan2(zy_n, zx_n); }
         if (tid < 2) sh_tw[tid] = tw_n;
         __syncthreads();
         fetch(t + 1);  // flies under this step's arithmetic
@@ -415,7 +416,8 @@ __global__ __launch_bounds__(THREADS) void k_pool_run_known(PoolView pv, const d
             if (lm < 0) break;            // uniform
             if (tid == 0) {
                 MeasTerms m;
-                measurement_terms(st[2 * lm + 3], st[2 * lm + 4], sh_z[2 * v], sh_z[2 * v + 1], theta, x, y, m);
+                m.z0 = sh_z[2 * v]; m.z1 = sh_z[2 * v + 1];
+                predicted_terms(st[2 * lm + 3], st[2 * lm + 4], theta, x, y, m);
                 double S55[5][5], Sm[2][2], Si[2][2];
                 for (int k = 0; k < 5; k++)
                     for (int l = 0; l < 5; l++) S55[k][l] = S[idx5(k, lm) * ldS + idx5(l, lm)];

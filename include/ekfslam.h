@@ -87,6 +87,10 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
  * scoring kernel.  scores_out: M doubles. */
 ekf_status ekf_maha_scores(ekf_handle h, double meas_x, double meas_y, int M, double* scores_out);
 
+/* double rigid2d::normalize_angle(double)            rigid2d/src/rigid2d.cpp:336-345 (range (-pi, pi]).
+ * Parity hook of the device helper every kernel uses: out[i] = normalize_angle(in[i]), count values. */
+ekf_status ekf_normalize_angles(int device, const double* in, int count, double* out);
+
 /* getStateTheta / getStateX / getStateY             ekf_slam.cpp:404-414 -> out = {theta, x, y} */
 ekf_status ekf_get_pose(ekf_handle h, double out[3]);
 /* mat getStateLandmark()                            ekf_slam.cpp:416-418 -> 2n doubles */

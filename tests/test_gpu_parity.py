@@ -496,3 +496,34 @@ def test_zero_landmark_filter(hip, oracle):
     assert f.getStateLandmark().size == 0
     assert np.abs(f.state - o.state).max() < 1e-14 and np.abs(f.cov - o.cov).max() < 1e-16
     f.close()
+
+
+def test_device_normalize_angle_bit_exact(hip, oracle):
+    """The device helper takes a shortcut for |rad| < 2*pi (fmod is exact there); it must equal the two-fmod form of
+    rigid2d.cpp:336-345 bit for bit -- against the C restatement and, where present, the reference build itself."""
+    import math
+    rng = np.random.default_rng(99)
+    two_pi, pi = 2 * math.pi, math.pi
+    edges = []
+    for c in (0.0, pi, -pi, two_pi, -two_pi, 2 * two_pi, -2 * two_pi, 3 * pi, -3 * pi, pi / 2):
+        x = c
+        for _ in range(4):
+            edges += [x, -x]
+            x = math.nextafter(x, math.inf)
+        x = c
+        for _ in range(4):
+            x = math.nextafter(x, -math.inf)
+            edges += [x, -x]
+    xs = np.concatenate([np.array(edges + [-0.0, 1e-300, -1e-300, 5e-324, 1e6, -1e6, 1e15, -1e15, 1e300]),
+                         rng.uniform(-7.0, 7.0, 200000), rng.uniform(-50.0, 50.0, 20000), rng.normal(0, 1e4, 2000)])
+    got = hip.normalize_angles(xs)
+    want = np.array([oracle.normalize_angle(float(x)) for x in xs])
+    assert np.array_equal(got, want), f"{int((got != want).sum())} values differ, first at x = {xs[np.argmax(got != want)]!r}"
+    assert np.array_equal(np.signbit(got), np.signbit(want))           # -0.0 handled alike
+    assert np.isnan(hip.normalize_angles(np.array([np.nan, np.inf, -np.inf]))).all()
+    try:
+        ref = oracle.RefRigid2D()
+    except FileNotFoundError:
+        return
+    sub = np.concatenate([xs[:200], xs[-300:]])
+    assert np.array_equal(hip.normalize_angles(sub), np.array([ref.normalize_angle(float(x)) for x in sub]))
