@@ -109,3 +109,72 @@ def test_largest_map_n5000(hip, oracle):
             f.prediction(log.twist[t, 0]); f.measurement(sensor, vis)
         assert_parity(f.state, f.cov, o.state, ocov, FP64_TOL, f"n=5000 update mode {k}")
         f.close()
+
+
+def test_batch_unknown_n1000_properties(hip, oracle):
+    """configs[2]'s world for a pool: prefix-confined run == full-width run bit for bit, known counts only grow,
+    every corrected index is a discovered one, and the association is RIGHT: a discovered landmark keeps pointing at
+    the tube that created it (the host log carries the generating tube of every reading)."""
+    cfg = synth.config3(steps=14)
+    cfg.filters = 6
+    log = synth.make_unknown_log(cfg)
+    out = []
+    for prefix in (True, False):
+        bt = hip.BatchEKF(cfg.filters, cfg.n)
+        bt.set_active_prefix(prefix)
+        bt.upload_unknown_log(log.twist, log.count, log.meas_xy)
+        kc_prev = np.zeros(cfg.filters, dtype=np.int32)
+        for t0 in range(0, cfg.steps, 7):
+            bt.run_unknown(t0, t0 + 7)
+            kc = bt.known_counts()
+            assert (kc >= kc_prev).all()
+            kc_prev = kc
+        out.append((bt.decisions().copy(), kc.copy(), bt.state(2), bt.cov(2), bt.poses()))
+        bt.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+    dec, kc = out[0][0], out[0][1]
+    wrong = total = 0
+    for b in range(cfg.filters):
+        owner = {}
+        for t in range(cfg.steps):
+            for j in range(int(log.count[t, b])):
+                lm, tube = int(dec[t, b, j]), int(log.truth_idx[t, b, j])
+                if lm < 0:
+                    continue
+                assert lm < kc[b]
+                total += 1
+                if owner.setdefault(lm, tube) != tube:
+                    wrong += 1
+    assert total > 400 and wrong == 0
+    o, known = oracle.OracleEKF(cfg.n, oracle.STRUCTURED), np.zeros(cfg.n, dtype=np.uint8)
+    for t in range(cfg.steps):
+        o.prediction(*log.twist[t, 2])
+        o.data_association(log.meas_xy[t, 2, :log.count[t, 2]], known)
+    assert_parity(out[0][2], out[0][3], o.state, o.cov, FP64_TOL, "batch unknown n=1000")
+    tp = log.true_pose[cfg.steps - 1]
+    assert np.abs(out[0][4][:, 1:] - tp[:, 1:]).max() < 0.2
+
+
+def test_small_map_monte_carlo_consistency(hip, oracle):
+    """The reference's own configuration (configs[0]) for 2048 robots in one launch: statistically consistent (the
+    NEES of a 3-dof pose error stays under the 95 % chi-square bound for nearly every robot) and equal to the CPU
+    checker on the sampled robots over the whole run."""
+    B, T, n = 2048, 300, 20
+    cfg = synth.config1(steps=T)
+    cfg.filters = B
+    world = synth.make_world(n, cfg.half_extent, cfg.min_spacing, cfg.seed)
+    bt = hip.BatchEKF(B, n)
+    bt.simulate_known_log(cfg, world, vmax=n)
+    st = bt.run_known()
+    assert st["rank2_launches"] == 1 and st["filter_steps"] == B * T
+    mc = bt.mc_stats(T - 1)
+    assert mc["frac_nees_below_95pct"] > 0.9 and mc["rmse_xy"] < 0.02 and mc["rmse_theta"] < 0.05
+    tw, li, zz, ii, _ = bt.download_log(want_truth=False)
+    for b in (0, 1023, 2047):
+        o = oracle.OracleEKF(n, oracle.STRUCTURED)
+        for t in range(T):
+            o.prediction(*tw[t, b])
+            o.measurement_compact(ii[b], li[t, b], zz[t, b])
+        assert_parity(bt.state(b), bt.cov(b), o.state, o.cov, FP64_TOL, f"small-map Monte-Carlo, robot {b}")
+    bt.close()
