@@ -1,0 +1,51 @@
+"""Extended differential check of the batched unknown-association run against the single-filter API (bit for bit):
+random pool sizes, map sizes, ragged measurement counts, split runs, LDS-resident / multi-kernel / prefix switches."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime)
+from ekf_slam_ml_amd import capi as hip
+
+bad = 0
+N_SCEN = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+for seed in range(N_SCEN):
+    rng = np.random.default_rng(70000 + seed)
+    B, n, T, J = int(rng.integers(1, 7)), int(rng.integers(3, 91)), int(rng.integers(4, 26)), int(rng.integers(1, 7))
+    world = rng.uniform(-2.5, 2.5, size=(max(n, 8), 2))
+    twist = np.stack([rng.normal(0, 0.2, (T, B)), rng.normal(0.05, 0.03, (T, B))], axis=2)
+    count = rng.integers(0, J + 1, size=(T, B)).astype(np.int32)
+    meas = np.zeros((T, B, J, 2))
+    pose = np.zeros((B, 3))
+    for t in range(T):
+        pose[:, 1] += twist[t, :, 1] * np.cos(pose[:, 0]); pose[:, 2] += twist[t, :, 1] * np.sin(pose[:, 0]); pose[:, 0] += twist[t, :, 0]
+        for b in range(B):
+            pick = rng.choice(len(world), size=J, replace=False)
+            d = world[pick] - pose[b, 1:]
+            c, s = np.cos(pose[b, 0]), np.sin(pose[b, 0])
+            meas[t, b] = np.stack([c * d[:, 0] + s * d[:, 1], -s * d[:, 0] + c * d[:, 1]], axis=1) + rng.normal(0, 0.004, (J, 2))
+    bt = hip.BatchEKF(B, n)
+    bt.set_small_map_path(bool(rng.integers(0, 2)))
+    bt.set_active_prefix(bool(rng.integers(0, 2)))
+    bt.upload_unknown_log(twist, count, meas)
+    cut = int(rng.integers(0, T + 1))
+    bt.run_unknown(0, cut); bt.run_unknown(cut, T)
+    dec, kc = bt.decisions(), bt.known_counts()
+    ok = True
+    for b in range(B):
+        f = hip.EKF_SLAM(n)
+        f.set_fused_correction(bool(rng.integers(0, 2)))
+        k = np.zeros(n, dtype=np.uint8)
+        for t in range(T):
+            f.prediction(twist[t, b])
+            a = f.data_association(meas[t, b, :count[t, b]], k)
+            ok &= np.array_equal(a, dec[t, b, :count[t, b]])
+        ok &= int(k.sum()) == int(kc[b]) and np.array_equal(f.state, bt.state(b)) and np.array_equal(f.cov, bt.cov(b))
+        f.close()
+    bt.close()
+    if not ok:
+        bad += 1
+        print(f"FAIL scenario {seed}: B={B} n={n} T={T} J={J}", flush=True)
+    if seed % 50 == 0:
+        print("scenario", seed, "failures so far", bad, flush=True)
+print("done, failures:", bad)
