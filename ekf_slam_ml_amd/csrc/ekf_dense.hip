@@ -186,7 +186,7 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
             }
 }
 
-// 79 x 79 = 6241 tiles do not divide the 1024 resident workgroup slots (6.09 rounds), so only the full
+// 79 x 79 = 6241 tiles do not divide the 768 resident workgroup slots (3 per CU: 8.13 rounds), so only the 8 full
 // rounds run as 128 x 128 tiles (k_gemm_f32); the last 97 tiles are cut into 64 x 64 quarters
 // (k_gemm_f32_tail, launched on a second stream so that its workgroups fill the slots the big kernel's
 // last round leaves idle) and end the product in a quarter of a tile time (speed only).
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_f32_tail(const float* __restric
 }
 
 // Measured at N = 10003 (tools/dense_bench.py): single buffer 123.6 TFLOP/s, double buffer 122.0 -- the
-// extra resident waves hide the second barrier, and 4 workgroups per CU need only 33 KB of LDS each.
+// extra resident waves hide the second barrier, and 3 workgroups per CU need only 33 KB of LDS each.
 static int g_dense_nbuf = 1;
 void dense_gemm_set_buffers(int nbuf) { g_dense_nbuf = nbuf == 1 ? 1 : 2; }
 
