@@ -100,3 +100,28 @@ def test_unknown_log_shape():
     cfg = synth.config1(steps=20)
     log = synth.make_unknown_log(cfg)
     assert log.meas_xy.shape == (20, 1, cfg.vmax, 2) and (log.count <= cfg.vmax).all() and log.count.sum() > 20
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r01/bench_n1.json is the line bench.py printed on the GPU box: every field of the driver's contract
+    must be there, with the roofline and cpu_baseline objects, and the numbers must be mutually consistent."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "r01", "bench_n1.json")
+    line = [l for l in open(path) if l.startswith("{")][0]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # whole-job throughput = corrections of the timed steps / wall time
+    corr = d["config"]["filters_per_gpu"] * d["config"]["corrections_per_filter_step"] * d["steps"]
+    assert abs(d["value"] - corr / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
