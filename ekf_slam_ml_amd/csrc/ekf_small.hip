@@ -1,4 +1,8 @@
-// ekf_small.hip -- single-workgroup, LDS-resident measurement() for small maps.
+// ekf_small.hip -- LDS-resident kernels for small maps and small discovered prefixes:
+//   k_small_measure     one measurement() call of one filter                       (single-filter API)
+//   k_small_associate   one data_association() call of one filter                  (single-filter API)
+//   k_pool_associate    one STEP of data_association() for every filter of a pool  (ekf_batch_run_unknown)
+//   k_pool_run_known    a whole RUN of prediction() + measurement() per filter     (ekf_batch_run_known)
 //
 // At the reference's own operating point (n = 20 landmarks, N = 43, nuslam/src/slam.cpp:250) the whole
 // covariance is 15 KB: streaming it through HBM with two launches per visible landmark is all launch
