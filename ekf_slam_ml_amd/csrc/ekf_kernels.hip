@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void k_measure_begin(PoolView pv, const double
 //   G  = H5 * Sigma[c5,:]                       (5 coalesced row reads per column)
 // Reads Sigma/state only, writes scratch (Kg, Gh, rec) only -> race-free across workgroups; the
 // state update state += K*nu (:186-187) happens in the rank-2 kernel, after the kernel boundary.
-// grid (ceil(ld/256), B), 256 threads.
+// grid (ceil((N + 1)/256), B), 256 threads: rows up to the active dimension N (a discovered prefix in
+// data_association(); each filter of a pool may narrow it further, CorrRec.n_active).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
     const int b = blockIdx.y;
@@ -525,7 +526,8 @@ __global__ void k_touch_all(PoolView pv) {
 // Mahalanobis scores, calculate_maha_dis() ekf_slam.cpp:217-276: ONE LANDMARK PER WAVEFRONT.
 // 25 lanes fetch the 5x5 sub-block Sigma[c5,c5] in one go; H*Sigma*H^T is folded with wave
 // shuffles in the CPU restatement's summation order; the innovation bearing is NOT wrapped (:269).
-// grid (ceil(n/4), B), 4 waves per workgroup.
+// grid (ceil(M/4), B), 4 waves per workgroup; M = host bound of the known count (n without one).  With
+// ms.terms the wave also leaves H, S^-1 and nu of its landmark for the correction of the winner.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_maha(PoolView pv, MeasSrc ms, double* scores, int m_override) {
     const int b = blockIdx.y;
