@@ -125,3 +125,21 @@ def test_committed_bench_line_keeps_the_contract():
     # whole-job throughput = corrections of the timed steps / wall time
     corr = d["config"]["filters_per_gpu"] * d["config"]["corrections_per_filter_step"] * d["steps"]
     assert abs(d["value"] - corr / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+
+
+def test_scan_generator_addressing():
+    """The host twin of the device lidar: noise is a pure function of (seed, filter id, step, beam); the default filter
+    id is the scan index; geometry is independent of the noise stream."""
+    from ekf_slam_ml_amd import synth
+    poses = np.array([[0.0, 0.0, 0.0], [1.0, 0.2, -0.3], [-2.0, -0.4, 0.5]])
+    a = synth.make_scans(poses, seed=5)
+    assert np.array_equal(a, synth.make_scans(poses, seed=5, fid=np.arange(3), step=0))
+    b = synth.make_scans(poses, seed=5, fid=[7, 8, 9], step=4)
+    clean = synth.make_scans(poses, seed=5, range_std=0.0)
+    assert not np.array_equal(a, b) and np.abs(a - clean).max() < 0.05 and np.abs(b - clean).max() < 0.05
+    assert np.array_equal(synth.make_scans(poses[1:2], seed=5, fid=[8], step=4)[0], b[1])   # scans are independent
+    assert a.shape == (3, 360) and (clean <= 3.5).all() and (clean > 0).all()
+    # a tube straight ahead of the first pose is hit at (distance - radius)
+    tube = np.array([[1.0, 0.0]])
+    r = synth.make_scans(poses[:1], world=tube, range_std=0.0, border=10.0)[0]
+    assert abs(r[0] - (1.0 - synth.TUBE_RADIUS)) < 1e-12 and r[180] == 3.5
