@@ -83,25 +83,32 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
 ekf_status ekf_predict(ekf_handle h, double dtheta, double dx) {
     if (!h) return fail(EKF_ERR_INVALID, "ekf_predict: null handle");
     Pool& P = h->pool;
-    EKFC(P.use());
-    // Rows/columns of landmarks this object never corrected are exactly zero against the pose block
-    // (constructor values), and At*0*At^T + 0 = 0: the propagation is confined to the touched prefix.
-    ekf::PoolView view = P.pv;
-    if (P.active_prefix && P.pend_cap == 0 && P.touched_hwm < P.pv.n) view.N = 3 + 2 * P.touched_hwm;
-    ekf::launch_predict(view, nullptr, dtheta, dx, P.pending(), P.stream);
+    EKFC(P.use());  // (a prediction still pending from the previous call happens now)
+    if (P.defer_predict_ok()) {  // small map: rides along with the next measurement() / data_association() launch
+        P.pred_pending = true;
+        P.pred_dth = dtheta;
+        P.pred_dx = dx;
+        return EKF_OK;
+    }
+    P.launch_predict_now(dtheta, dx);
     return checked_launch();
 }
 
 ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_t* visible) {
     if (!h || !sensor_xy || !visible) return fail(EKF_ERR_INVALID, "ekf_measure_known: null argument");
     Pool& P = h->pool;
-    EKFC(P.use());
+    EKFC(P.use(false));
     const int n = P.pv.n;
-    EKFC(P.upload2(P.sensor_dev, sensor_xy, sizeof(double) * 2 * n, visible, (size_t)n));
-    if (P.small_path && P.pend_cap == 0 && P.pv.N <= ekf::small_max_dim() && n > 0) {
-        // small map (the reference runs n = 20): the whole call in one LDS-resident launch
+    const bool small = P.small_path && P.pend_cap == 0 && P.pv.N <= ekf::small_max_dim() && n > 0;
+    if (small && n <= ekf::kSmallInlineN) {
+        // small map (the reference runs n = 20): the whole call -- and the prediction() before it -- in one
+        // LDS-resident launch whose inputs travel by value in the kernel arguments (no staging, no copy)
         P.alt_synced = false;
-        ekf::launch_small_measure(P.pv, P.sensor_dev, P.visible_dev, !P.init_flag, P.stream);
+        ekf::SmallInline in;
+        std::memcpy(in.sensor, sensor_xy, sizeof(double) * 2 * n);
+        std::memcpy(in.visible, visible, (size_t)n);
+        ekf::launch_small_measure_inline(P.pv, in, !P.init_flag, P.pred_pending, P.pred_dth, P.pred_dx, P.stream);
+        P.pred_pending = false;
         P.init_flag = 1;
         for (int i = n - 1; i >= 0; i--)
             if (visible[i]) { if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1; break; }
@@ -109,6 +116,20 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
             if (visible[i]) P.note_touched(i);
         return checked_launch();
     }
+    EKFC(P.upload2(P.sensor_dev, sensor_xy, sizeof(double) * 2 * n, visible, (size_t)n));
+    if (small) {
+        P.alt_synced = false;
+        ekf::launch_small_measure(P.pv, P.sensor_dev, P.visible_dev, !P.init_flag, P.pred_pending, P.pred_dth, P.pred_dx,
+                                  P.stream);
+        P.pred_pending = false;
+        P.init_flag = 1;
+        for (int i = n - 1; i >= 0; i--)
+            if (visible[i]) { if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1; break; }
+        for (int i = 0; i < n; i++)
+            if (visible[i]) P.note_touched(i);
+        return checked_launch();
+    }
+    EKFC(P.use());  // settles a deferred prediction()
     // ekf_slam.cpp:109-128.  The pose capture needs its own launch only together with the first-call
     // landmark initialisation; afterwards the first correction of the call records the pose it reads
     // (no correction has moved it yet) and the later ones use that record.
@@ -150,7 +171,7 @@ static ekf_status associate_finish(Pool& P, int known_count, int J, uint8_t* kno
 ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* known, int* assoc_out) {
     if (!h || !known || J < 0 || (J > 0 && !meas_xy)) return fail(EKF_ERR_INVALID, "ekf_associate: bad argument");
     Pool& P = h->pool;
-    EKFC(P.use());
+    EKFC(P.use(false));
     const int n = P.pv.n;
     int known_count = 0;  // ekf_slam.cpp:281-288: leading run of true
     for (int i = 0; i < n; i++) {
@@ -159,14 +180,28 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     if (J == 0) return EKF_OK;
     EKFC(P.flush());  // the scoring kernel reads Sigma directly
     EKFC(P.ensure_meas_capacity(J));
+    if (P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && J <= ekf::kSmallInlineJ) {
+        // small map: the whole call (and the prediction() before it) in one LDS-resident launch, measurements by value
+        P.alt_synced = false;
+        ekf::SmallInlineMeas in;
+        std::memcpy(in.xy, meas_xy, sizeof(double) * 2 * J);
+        ekf::launch_small_associate_inline(P.pv, in, J, known_count, P.assoc_out_dev, P.pred_pending, P.pred_dth, P.pred_dx,
+                                           P.stream);
+        P.pred_pending = false;
+        EKFC(checked_launch());
+        return associate_finish(P, known_count, J, known, assoc_out);
+    }
     EKFC(P.upload(P.meas_dev, meas_xy, sizeof(double) * 2 * J));
     if (P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && n <= 128) {
         // small map: scores, decisions and corrections of all J measurements in one LDS-resident launch
         P.alt_synced = false;
-        ekf::launch_small_associate(P.pv, P.meas_dev, J, known_count, P.assoc_out_dev, P.stream);
+        ekf::launch_small_associate(P.pv, P.meas_dev, J, known_count, P.assoc_out_dev, P.pred_pending, P.pred_dth,
+                                    P.pred_dx, P.stream);
+        P.pred_pending = false;
         EKFC(checked_launch());
         return associate_finish(P, known_count, J, known, assoc_out);
     }
+    EKFC(P.use());  // settles a deferred prediction()
     // known_count lives on the device between calls (the node only ever passes back the list this function
     // returned); it is rewritten only when the caller's list says something else
     if (known_count != P.dev_known_count) ekf::launch_assoc_begin(P.pv, nullptr, known_count, P.stream);

@@ -255,10 +255,23 @@ int circles_max_beams();
 int circles_max_clusters();
 // whole measurement() call of a SMALL map in one single-workgroup, LDS-resident launch (ekf_small.hip)
 void launch_small_measure(const PoolView& pv, const double* sensor, const unsigned char* visible, int do_init,
-                          hipStream_t s);
-// whole data_association() call of a small map (single filter: pv.B == 1) in one launch
+                          int has_twist, double dtheta, double dx, hipStream_t s);
+// The same for ONE filter with the inputs passed BY VALUE in the kernel-argument segment (n <= kSmallInlineN):
+// no staging buffer, no host-to-device copy, no copy -> kernel dependency in the stream.
+constexpr int kSmallInlineN = 50;
+struct SmallInline {
+    double sensor[2 * kSmallInlineN];
+    unsigned char visible[kSmallInlineN + 6];
+};
+void launch_small_measure_inline(const PoolView& pv, const SmallInline& in, int do_init, int has_twist, double dtheta,
+                                 double dx, hipStream_t s);
+constexpr int kSmallInlineJ = 32;
+struct SmallInlineMeas { double xy[2 * kSmallInlineJ]; };  // the measures vector of data_association(), by value
+void launch_small_associate_inline(const PoolView& pv, const SmallInlineMeas& in, int J, int known_count, int* assoc_out,
+                                   int has_twist, double dtheta, double dx, hipStream_t s);
+// (has_twist: a prediction(dtheta, dx) deferred by the host runs first, on the LDS image)
 void launch_small_associate(const PoolView& pv, const double* meas, int J, int known_count, int* assoc_out,
-                            hipStream_t s);
+                            int has_twist, double dtheta, double dx, hipStream_t s);
 // one step of an unknown-association log for a pool whose every discovered prefix fits the small path:
 // pv.N = the pool-wide bound of 3 + 2*(known_count + count) (<= small_max_dim()); meas [B][jmax][2], count [B]
 void launch_pool_associate(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,

@@ -264,8 +264,28 @@ struct Pool {
         }
     }
 
-    ekf_status use() {
+    // Small single filters: prediction() is not launched by itself but handed to the LDS-resident launch of the
+    // measurement() / data_association() call that follows it in the node loop (one launch per step instead of
+    // two).  Anything else that looks at the filter first makes it happen: every entry point passes through use().
+    bool pred_pending = false;
+    double pred_dth = 0.0, pred_dx = 0.0;
+    bool defer_predict_ok() const {
+        return pv.B == 1 && small_path && pend_cap == 0 && pv.n > 0 && pv.N <= ekf::small_max_dim();
+    }
+    void launch_predict_now(double dth, double dx) {
+        // Rows/columns of landmarks this object never corrected are exactly zero against the pose block
+        // (constructor values), and At*0*At^T + 0 = 0: the propagation is confined to the touched prefix.
+        ekf::PoolView view = pv;
+        if (active_prefix && pend_cap == 0 && touched_hwm < pv.n) view.N = 3 + 2 * touched_hwm;
+        ekf::launch_predict(view, nullptr, dth, dx, pending(), stream);
+    }
+    ekf_status use(bool settle = true) {
         HIPC(hipSetDevice(device));
+        if (settle && pred_pending) {
+            pred_pending = false;
+            launch_predict_now(pred_dth, pred_dx);
+            HIPC(hipGetLastError());
+        }
         return EKF_OK;
     }
 

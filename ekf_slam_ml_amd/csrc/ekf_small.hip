@@ -18,13 +18,74 @@
 
 namespace ekf {
 
-constexpr int kSmallThreads = 256;
 
-__global__ __launch_bounds__(kSmallThreads) void k_small_measure(PoolView pv, const double* __restrict__ sensor,
-                                                                 const unsigned char* __restrict__ visible,
-                                                                 int do_init) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// prediction() on the LDS image (ekf_slam.cpp:55-106): the structured arithmetic of k_predict, operation for
+// operation.  Every thread of the workgroup calls it; the image must be complete on entry (barrier before), and is
+// consistent on return (barrier inside).
+template <int THREADS>
+__device__ __forceinline__ void small_predict(double* S, double* st, int ldS, int N, double dtheta, double dx,
+                                              const Params& prm) {
+    const int tid = threadIdx.x;
+    const double theta = st[0];
+    double u0, u1, u2, a10, a20;
+    if (fabs(dtheta) < prm.straight_eps) {  // :79-86
+        u0 = 0;
+        u1 = dx * cos(theta);
+        u2 = dx * sin(theta);
+        a10 = -dx * sin(theta);
+        a20 = dx * cos(theta);
+    } else {  // :88-94
+        u0 = dtheta;
+        u1 = -(dx / dtheta) * sin(theta) + (dx / dtheta) * sin(theta + dtheta);
+        u2 = (dx / dtheta) * cos(theta) - (dx / dtheta) * cos(theta + dtheta);
+        a10 = -(dx / dtheta) * cos(theta) + (dx / dtheta) * cos(theta + dtheta);
+        a20 = -(dx / dtheta) * sin(theta) + (dx / dtheta) * sin(theta + dtheta);
+    }
+    double c[3][3], px = 0.0, py = 0.0;
+    if (tid == 0) {
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) c[r][k] = S[r * ldS + k];
+        px = st[1]; py = st[2];
+    }
+    __syncthreads();  // all threads hold the old theta; thread 0 may now move the pose
+    for (int k = 3 + tid; k < N; k += THREADS) {
+        const double q0 = S[0 * ldS + k], q1 = S[1 * ldS + k], q2 = S[2 * ldS + k];
+        double* rowk = S + k * ldS;
+        const double r0 = rowk[0], r1 = rowk[1], r2 = rowk[2];
+        S[1 * ldS + k] = a10 * q0 + q1;
+        S[2 * ldS + k] = a20 * q0 + q2;
+        rowk[1] = r0 * a10 + r1;
+        rowk[2] = r0 * a20 + r2;
+    }
+    if (tid == 0) {
+        st[0] = theta + u0;  // :99 -- theta is NOT wrapped after the prediction
+        st[1] = px + u1;
+        st[2] = py + u2;
+        double T[3][3];
+        for (int k = 0; k < 3; k++) {
+            T[0][k] = c[0][k];
+            T[1][k] = a10 * c[0][k] + c[1][k];
+            T[2][k] = a20 * c[0][k] + c[2][k];
+        }
+        for (int r = 0; r < 3; r++) {
+            S[r * ldS + 0] = T[r][0];
+            S[r * ldS + 1] = T[r][0] * a10 + T[r][1];
+            S[r * ldS + 2] = T[r][0] * a20 + T[r][2];
+        }
+        S[0] += prm.q_pose;  // Q = diag(q,q,q,0...) :40-43
+        S[1 * ldS + 1] += prm.q_pose;
+        S[2 * ldS + 2] += prm.q_pose;
+    }
+    __syncthreads();
+}
+
+
+// has_twist: a prediction(dtheta, dx) the host deferred into this launch runs first, on the LDS image.
+template <int THREADS>
+__device__ __forceinline__ void small_measure_body(const PoolView& pv, int b, const double* __restrict__ sens,
+                                                   const unsigned char* __restrict__ vis, int do_init, int has_twist,
+                                                   double dtheta, double dx, double* sm) {
+    const int tid = threadIdx.x;
     const int N = pv.N, ld = pv.ld, n = pv.n;
     const int ldS = N | 1;
     double* S = sm;            // [N][ldS]
@@ -34,17 +95,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_measure(PoolView pv, co
 
     double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
     double* stg = pv.state + (size_t)b * ld;
-    const double* sens = sensor + (size_t)b * 2 * n;
-    const unsigned char* vis = visible + (size_t)b * n;
-    for (int r = tid >> 6; r < N; r += kSmallThreads / 64)
+    for (int r = tid >> 6; r < N; r += THREADS / 64)
         for (int c = tid & 63; c < N; c += 64) S[r * ldS + c] = Sg[(size_t)r * ld + c];
-    for (int r = tid; r < N; r += kSmallThreads) st[r] = stg[r];
+    for (int r = tid; r < N; r += THREADS) st[r] = stg[r];
     __syncthreads();
+    if (has_twist) small_predict<THREADS>(S, st, ldS, N, dtheta, dx, pv.p);  // uniform
 
     const double theta = st[0], x = st[1], y = st[2];  // captured ONCE, ekf_slam.cpp:109-111
     if (do_init) {                                     // :113-128, all n landmarks regardless of visibility
         __syncthreads();                               // everybody holds the pose before the map is rewritten
-        for (int i = tid; i < n; i += kSmallThreads) {
+        for (int i = tid; i < n; i += THREADS) {
             const double sx = sens[2 * i], sy = sens[2 * i + 1];
             const double ri = sqrt(sx * sx + sy * sy);
             const double phii = atan2(sy, sx);
@@ -103,9 +163,27 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_measure(PoolView pv, co
         __syncthreads();
     }
 
-    for (int r = tid >> 6; r < N; r += kSmallThreads / 64)
+    for (int r = tid >> 6; r < N; r += THREADS / 64)
         for (int c = tid & 63; c < N; c += 64) Sg[(size_t)r * ld + c] = S[r * ldS + c];
-    for (int r = tid; r < N; r += kSmallThreads) stg[r] = st[r];
+    for (int r = tid; r < N; r += THREADS) stg[r] = st[r];
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_small_measure(PoolView pv, const double* __restrict__ sensor,
+                                                           const unsigned char* __restrict__ visible, int do_init,
+                                                           int has_twist, double dtheta, double dx) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = blockIdx.x;
+    small_measure_body<THREADS>(pv, b, sensor + (size_t)b * 2 * pv.n, visible + (size_t)b * pv.n, do_init, has_twist,
+                                dtheta, dx, sm);
+}
+
+// One filter, inputs by value: `in` lives in the kernel-argument segment the launch packet already carries.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_small_measure_inline(PoolView pv, SmallInline in, int do_init,
+                                                                  int has_twist, double dtheta, double dx) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    small_measure_body<THREADS>(pv, 0, in.sensor, in.visible, do_init, has_twist, dtheta, dx, sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -119,7 +197,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_measure(PoolView pv, co
 // returns (on every lane) the number of corrections applied.
 template <int THREADS>
 __device__ int small_associate_body(const PoolView& pv, int b, int N, const double* __restrict__ meas, int J,
-                                    int known_count_in, int* __restrict__ assoc_out, double* sm) {
+                                    int known_count_in, int* __restrict__ assoc_out, double* sm, int has_twist = 0,
+                                    double dtheta = 0.0, double dx = 0.0) {
     const int tid = threadIdx.x;
     const int ld = pv.ld, n = pv.n;
     const int ldS = N | 1;
@@ -136,6 +215,7 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
     for (int r = tid; r < N; r += THREADS) st[r] = stg[r];
     if (tid == 0) { sh_M = known_count_in; sh_applied = 0; }
     __syncthreads();
+    if (has_twist) small_predict<THREADS>(S, st, ldS, N, dtheta, dx, pv.p);  // a deferred prediction() (uniform)
 
     for (int j = 0; j < J; j++) {                       // :291 sequential, state-carrying
         const double mx = meas[2 * j], my = meas[2 * j + 1];
@@ -262,9 +342,18 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_small_associate(PoolView pv, const double* __restrict__ meas, int J,
-                                                             int known_count_in, int* __restrict__ assoc_out) {
+                                                             int known_count_in, int* __restrict__ assoc_out,
+                                                             int has_twist, double dtheta, double dx) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    small_associate_body<THREADS>(pv, blockIdx.x, pv.N, meas, J, known_count_in, assoc_out, sm);
+    small_associate_body<THREADS>(pv, blockIdx.x, pv.N, meas, J, known_count_in, assoc_out, sm, has_twist, dtheta, dx);
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_small_associate_inline(PoolView pv, SmallInlineMeas in, int J,
+                                                                    int known_count_in, int* __restrict__ assoc_out,
+                                                                    int has_twist, double dtheta, double dx) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    small_associate_body<THREADS>(pv, 0, pv.N, in.xy, J, known_count_in, assoc_out, sm, has_twist, dtheta, dx);
 }
 
 // The same for a whole pool and one step of an unknown-association log: filter b takes its count[b] readings,
@@ -344,61 +433,7 @@ __global__ __launch_bounds__(THREADS) void k_pool_run_known(PoolView pv, const d
         __syncthreads();
         fetch(t + 1);  // flies under this step's arithmetic
 
-        // ---- prediction(), ekf_slam.cpp:55-106 (k_predict) ----
-        {
-            const double dtheta = sh_tw[0], dx = sh_tw[1];
-            const double theta = st[0];
-            double u0, u1, u2, a10, a20;
-            if (fabs(dtheta) < pv.p.straight_eps) {  // :79-86
-                u0 = 0;
-                u1 = dx * cos(theta);
-                u2 = dx * sin(theta);
-                a10 = -dx * sin(theta);
-                a20 = dx * cos(theta);
-            } else {  // :88-94
-                u0 = dtheta;
-                u1 = -(dx / dtheta) * sin(theta) + (dx / dtheta) * sin(theta + dtheta);
-                u2 = (dx / dtheta) * cos(theta) - (dx / dtheta) * cos(theta + dtheta);
-                a10 = -(dx / dtheta) * cos(theta) + (dx / dtheta) * cos(theta + dtheta);
-                a20 = -(dx / dtheta) * sin(theta) + (dx / dtheta) * sin(theta + dtheta);
-            }
-            double c[3][3], px = 0.0, py = 0.0;
-            if (tid == 0) {
-                for (int r = 0; r < 3; r++)
-                    for (int k = 0; k < 3; k++) c[r][k] = S[r * ldS + k];
-                px = st[1]; py = st[2];
-            }
-            __syncthreads();  // all threads hold the old theta; thread 0 may now move the pose
-            for (int k = 3 + tid; k < N; k += THREADS) {
-                const double q0 = S[0 * ldS + k], q1 = S[1 * ldS + k], q2 = S[2 * ldS + k];
-                double* rowk = S + k * ldS;
-                const double r0 = rowk[0], r1 = rowk[1], r2 = rowk[2];
-                S[1 * ldS + k] = a10 * q0 + q1;
-                S[2 * ldS + k] = a20 * q0 + q2;
-                rowk[1] = r0 * a10 + r1;
-                rowk[2] = r0 * a20 + r2;
-            }
-            if (tid == 0) {
-                st[0] = theta + u0;  // :99 -- theta is NOT wrapped after the prediction
-                st[1] = px + u1;
-                st[2] = py + u2;
-                double T[3][3];
-                for (int k = 0; k < 3; k++) {
-                    T[0][k] = c[0][k];
-                    T[1][k] = a10 * c[0][k] + c[1][k];
-                    T[2][k] = a20 * c[0][k] + c[2][k];
-                }
-                for (int r = 0; r < 3; r++) {
-                    S[r * ldS + 0] = T[r][0];
-                    S[r * ldS + 1] = T[r][0] * a10 + T[r][1];
-                    S[r * ldS + 2] = T[r][0] * a20 + T[r][2];
-                }
-                S[0] += pv.p.q_pose;  // Q = diag(q,q,q,0...) :40-43
-                S[1 * ldS + 1] += pv.p.q_pose;
-                S[2 * ldS + 2] += pv.p.q_pose;
-            }
-            __syncthreads();
-        }
+        small_predict<THREADS>(S, st, ldS, N, sh_tw[0], sh_tw[1], pv.p);  // prediction(), ekf_slam.cpp:55-106
 
         // ---- measurement(), ekf_slam.cpp:108-197 ----
         const double theta = st[0], x = st[1], y = st[2];  // captured ONCE per call, :109-111
@@ -472,13 +507,17 @@ __global__ __launch_bounds__(THREADS) void k_pool_run_known(PoolView pv, const d
 }
 
 size_t small_lds_bytes(int N) { return sizeof(double) * ((size_t)N * (N | 1) + 3 * (size_t)N); }
-int small_max_dim() { return kSmallThreads < 104 ? kSmallThreads : 104; }  // N <= 104: 87 KB of LDS, one lane per row
+int small_max_dim() { return 104; }  // N <= 104: 87 KB of LDS, one lane per row (128-thread workgroups)
 
 hipError_t small_prepare() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_measure),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(small_max_dim()));
-    if (e != hipSuccess) return e;
-    for (const void* f : {reinterpret_cast<const void*>(&k_small_associate<64>),
+    hipError_t e = hipSuccess;
+    for (const void* f : {reinterpret_cast<const void*>(&k_small_measure<64>),
+                          reinterpret_cast<const void*>(&k_small_measure<128>),
+                          reinterpret_cast<const void*>(&k_small_measure_inline<64>),
+                          reinterpret_cast<const void*>(&k_small_measure_inline<128>),
+                          reinterpret_cast<const void*>(&k_small_associate_inline<64>),
+                          reinterpret_cast<const void*>(&k_small_associate_inline<128>),
+                          reinterpret_cast<const void*>(&k_small_associate<64>),
                           reinterpret_cast<const void*>(&k_small_associate<128>),
                           reinterpret_cast<const void*>(&k_pool_associate<64>),
                           reinterpret_cast<const void*>(&k_pool_associate<128>)}) {
@@ -517,19 +556,43 @@ void launch_pool_associate(const PoolView& pv, const double* meas, const int* co
 }
 
 void launch_small_associate(const PoolView& pv, const double* meas, int J, int known_count, int* assoc_out,
-                            hipStream_t s) {
+                            int has_twist, double dtheta, double dx, hipStream_t s) {
     if (pv.N <= 64)
         hipLaunchKernelGGL(k_small_associate<64>, dim3(pv.B), dim3(64), small_lds_bytes(pv.N), s, pv, meas, J, known_count,
-                           assoc_out);
+                           assoc_out, has_twist, dtheta, dx);
     else
         hipLaunchKernelGGL(k_small_associate<128>, dim3(pv.B), dim3(128), small_lds_bytes(pv.N), s, pv, meas, J,
-                           known_count, assoc_out);
+                           known_count, assoc_out, has_twist, dtheta, dx);
+}
+
+void launch_small_associate_inline(const PoolView& pv, const SmallInlineMeas& in, int J, int known_count, int* assoc_out,
+                                   int has_twist, double dtheta, double dx, hipStream_t s) {
+    if (pv.N <= 64)
+        hipLaunchKernelGGL(k_small_associate_inline<64>, dim3(1), dim3(64), small_lds_bytes(pv.N), s, pv, in, J, known_count,
+                           assoc_out, has_twist, dtheta, dx);
+    else
+        hipLaunchKernelGGL(k_small_associate_inline<128>, dim3(1), dim3(128), small_lds_bytes(pv.N), s, pv, in, J,
+                           known_count, assoc_out, has_twist, dtheta, dx);
+}
+
+void launch_small_measure_inline(const PoolView& pv, const SmallInline& in, int do_init, int has_twist, double dtheta,
+                                 double dx, hipStream_t s) {
+    if (pv.N <= 64)
+        hipLaunchKernelGGL(k_small_measure_inline<64>, dim3(1), dim3(64), small_lds_bytes(pv.N), s, pv, in, do_init,
+                           has_twist, dtheta, dx);
+    else
+        hipLaunchKernelGGL(k_small_measure_inline<128>, dim3(1), dim3(128), small_lds_bytes(pv.N), s, pv, in, do_init,
+                           has_twist, dtheta, dx);
 }
 
 void launch_small_measure(const PoolView& pv, const double* sensor, const unsigned char* visible, int do_init,
-                          hipStream_t s) {
-    hipLaunchKernelGGL(k_small_measure, dim3(pv.B), dim3(kSmallThreads), small_lds_bytes(pv.N), s, pv, sensor, visible,
-                       do_init);
+                          int has_twist, double dtheta, double dx, hipStream_t s) {
+    if (pv.N <= 64)
+        hipLaunchKernelGGL(k_small_measure<64>, dim3(pv.B), dim3(64), small_lds_bytes(pv.N), s, pv, sensor, visible, do_init,
+                           has_twist, dtheta, dx);
+    else
+        hipLaunchKernelGGL(k_small_measure<128>, dim3(pv.B), dim3(128), small_lds_bytes(pv.N), s, pv, sensor, visible,
+                           do_init, has_twist, dtheta, dx);
 }
 
 }  // namespace ekf

@@ -6,6 +6,7 @@
 //   SLAM::callback_scan_sensor       nuslam/src/unknown_data_assoc.cpp:309-320
 //   SLAM::main_loop (INIT / UPDATE)  nuslam/src/slam.cpp:419-448, unknown_data_assoc.cpp:402-429
 // Input: a text log written by tests/test_gpu_host_cpp.py; output: state, covariance, known_list.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -106,12 +107,20 @@ int main(int argc, char** argv) {
         Odometer odo{wb, wr};
         SLAM node(n, unknown != 0, odo);
         node.main_loop();  // INIT tick
-        for (int t = 0; t < T; t++) {
+        // the whole log is parsed first so that the loop below times the node logic + filter calls only
+        struct Step { double dl, dr; std::vector<Marker> ms; };
+        std::vector<Step> steps(T);
+        for (Step& st : steps) {
             int count = 0;
-            if (std::fscanf(f, "%la %la %d", &odo.delta_left, &odo.delta_right, &count) != 3) return 2;
-            std::vector<Marker> ms(count);
-            for (Marker& m : ms)
+            if (std::fscanf(f, "%la %la %d", &st.dl, &st.dr, &count) != 3) return 2;
+            st.ms.resize(count);
+            for (Marker& m : st.ms)
                 if (std::fscanf(f, "%d %la %la %d", &m.id, &m.x, &m.y, &m.add) != 4) return 2;
+        }
+        const auto t_start = std::chrono::steady_clock::now();
+        for (int t = 0; t < T; t++) {
+            odo.delta_left = steps[t].dl; odo.delta_right = steps[t].dr;
+            const std::vector<Marker>& ms = steps[t].ms;
             if (unknown == 2) {  // markers carry raw laser ranges in .x: the landmarks node runs first
                 std::vector<double> ranges(ms.size());
                 for (size_t i = 0; i < ms.size(); i++) ranges[i] = ms[i].x;
@@ -122,6 +131,9 @@ int main(int argc, char** argv) {
             node.main_loop();  // a timer tick without new sensor data must be a no-op on the filter
         }
         std::fclose(f);
+        (void)node.slam_agent.getStateX();  // drains the stream
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        std::fprintf(stderr, "slam_replay: %d steps in %.3f s = %.0f steps/s (C++ node loop over the C ABI)\n", T, secs, T / secs);
         // rule of five: a copy must carry the device state, the original must survive the copy's death
         EKF_SLAM copy = node.slam_agent;
         { EKF_SLAM moved = std::move(copy); copy = moved; }
