@@ -114,11 +114,21 @@ __device__ __forceinline__ void small_measure_body(const PoolView& pv, int b, co
         __syncthreads();
     }
 
+    // (r, phi) of every visible reading at once, one landmark per lane (:142-146); n <= 50 on this path
+    __shared__ double sh_zr[64], sh_zp[64];
+    for (int i = tid; i < n; i += THREADS)
+        if (vis[i]) {
+            const double sx = sens[2 * i], sy = sens[2 * i + 1];
+            sh_zr[i] = sqrt(sx * sx + sy * sy);
+            sh_zp[i] = atan2(sy, sx);
+        }
+    __syncthreads();
     for (int lm = 0; lm < n; lm++) {  // :132-194 (uniform loop: every lane sees the same visible[] byte)
         if (!vis[lm]) continue;
         if (tid == 0) {
             MeasTerms m;
-            measurement_terms(st[2 * lm + 3], st[2 * lm + 4], sens[2 * lm], sens[2 * lm + 1], theta, x, y, m);
+            m.z0 = sh_zr[lm]; m.z1 = sh_zp[lm];
+            predicted_terms(st[2 * lm + 3], st[2 * lm + 4], theta, x, y, m);
             double S55[5][5], Sm[2][2], Si[2][2];
             for (int k = 0; k < 5; k++)
                 for (int l = 0; l < 5; l++) S55[k][l] = S[idx5(k, lm) * ldS + idx5(l, lm)];
