@@ -19,6 +19,19 @@
 namespace ekf {
 
 
+// First touches are recorded in LDS while the corrections run and written out once at the end, one landmark per
+// lane: touch_landmark()'s global read-modify-write would sit on the single lane's critical path of every correction.
+// (The order of a filter's touch list is irrelevant: k_rank2_active treats its rows independently.)
+__device__ __forceinline__ void flush_touches(const PoolView& pv, int b, const unsigned char* sh_touch, int n, int nthreads) {
+    unsigned char* tf = pv.touch_flag + (size_t)b * pv.n;
+    for (int i = threadIdx.x; i < n; i += nthreads)
+        if (sh_touch[i] && !tf[i]) {
+            tf[i] = 1;
+            const int slot = atomicAdd(&pv.touch_count[b], 1);
+            pv.touch_list[(size_t)b * pv.n + slot] = i;
+        }
+}
+
 // prediction() on the LDS image (ekf_slam.cpp:55-106): the structured arithmetic of k_predict, operation for
 // operation.  Every thread of the workgroup calls it; the image must be complete on entry (barrier before), and is
 // consistent on return (barrier inside).
@@ -116,6 +129,8 @@ __device__ __forceinline__ void small_measure_body(const PoolView& pv, int b, co
 
     // (r, phi) of every visible reading at once, one landmark per lane (:142-146); n <= 50 on this path
     __shared__ double sh_zr[64], sh_zp[64];
+    __shared__ unsigned char sh_touch[64];
+    if (tid < 64) sh_touch[tid] = 0;
     for (int i = tid; i < n; i += THREADS)
         if (vis[i]) {
             const double sx = sens[2 * i], sy = sens[2 * i + 1];
@@ -139,7 +154,7 @@ __device__ __forceinline__ void small_measure_body(const PoolView& pv, int b, co
             sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
             sh_nu[0] = m.z0 - m.zh0;                   // :182
             sh_nu[1] = normalize_angle(m.z1 - m.zh1);  // :183
-            touch_landmark(pv, b, lm);
+            sh_touch[lm] = 1;
         }
         __syncthreads();
         double k0 = 0.0, k1 = 0.0;
@@ -164,8 +179,12 @@ __device__ __forceinline__ void small_measure_body(const PoolView& pv, int b, co
         __syncthreads();
         // Sigma <- (I - K H) Sigma (:191-192): lane tid owns row tid's K, so rows are walked by their owner
         if (r < N) {
-            double* row = S + r * ldS;
-            for (int c = 0; c < N; c++) row[c] = row[c] - (k0 * Gg[c] + k1 * Gg[N + c]);
+            // (row and the two G rows never overlap: lets the LDS reads of later columns start before earlier writes)
+            double* __restrict__ row = S + r * ldS;
+            const double* __restrict__ G0 = Gg;
+            const double* __restrict__ G1 = Gg + N;
+#pragma unroll 4
+            for (int c = 0; c < N; c++) row[c] = row[c] - (k0 * G0[c] + k1 * G1[c]);
             double s = st[r] + (k0 * sh_nu[0] + k1 * sh_nu[1]);  // :186
             if (r == 0) s = normalize_angle(s);                  // :187
             st[r] = s;
@@ -176,6 +195,7 @@ __device__ __forceinline__ void small_measure_body(const PoolView& pv, int b, co
     for (int r = tid >> 6; r < N; r += THREADS / 64)
         for (int c = tid & 63; c < N; c += 64) Sg[(size_t)r * ld + c] = S[r * ldS + c];
     for (int r = tid; r < N; r += THREADS) stg[r] = st[r];
+    flush_touches(pv, b, sh_touch, n, THREADS);
 }
 
 template <int THREADS>
@@ -217,6 +237,8 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
     double* Gg = st + N;
     __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
     __shared__ int sh_M, sh_lm, sh_new, sh_applied;
+    __shared__ unsigned char sh_touch[64];
+    if (tid < 64) sh_touch[tid] = 0;
 
     double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
     double* stg = pv.state + (size_t)b * ld;
@@ -280,7 +302,7 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
             sh_lm = active ? idx : -1;
             sh_new = is_new;
             assoc_out[j] = sh_lm;
-            if (active) { sh_applied++; touch_landmark(pv, b, idx); }
+            if (active) { sh_applied++; sh_touch[idx] = 1; }
         }
         __syncthreads();
         const int lm = sh_lm;
@@ -329,8 +351,12 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
         }
         __syncthreads();
         if (r < N) {
-            double* row = S + r * ldS;
-            for (int c = 0; c < N; c++) row[c] = row[c] - (k0 * Gg[c] + k1 * Gg[N + c]);
+            // (row and the two G rows never overlap: lets the LDS reads of later columns start before earlier writes)
+            double* __restrict__ row = S + r * ldS;
+            const double* __restrict__ G0 = Gg;
+            const double* __restrict__ G1 = Gg + N;
+#pragma unroll 4
+            for (int c = 0; c < N; c++) row[c] = row[c] - (k0 * G0[c] + k1 * G1[c]);
             double s = st[r] + (k0 * sh_nu[0] + k1 * sh_nu[1]);
             if (r == 0) s = normalize_angle(s);
             st[r] = s;
@@ -346,6 +372,7 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
         a.known_count = sh_M; a.lm = sh_lm; a.active = sh_lm >= 0; a.pad = 0; a.best = 0.0;
         pv.assoc[b] = a;
     }
+    flush_touches(pv, b, sh_touch, n < 64 ? n : 64, THREADS);
     __syncthreads();
     return sh_applied;
 }
@@ -416,6 +443,8 @@ __global__ __launch_bounds__(THREADS) void k_pool_run_known(PoolView pv, const d
     __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
     __shared__ double sh_tw[2], sh_z[2 * 64];
     __shared__ int sh_lmv[64];
+    __shared__ unsigned char sh_touch[64];
+    if (tid < 64) sh_touch[tid] = 0;
 
     double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
     double* stg = pv.state + (size_t)b * ld;
@@ -477,7 +506,7 @@ __global__ __launch_bounds__(THREADS) void k_pool_run_known(PoolView pv, const d
                 sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
                 sh_nu[0] = m.z0 - m.zh0;                   // :182
                 sh_nu[1] = normalize_angle(m.z1 - m.zh1);  // :183
-                touch_landmark(pv, b, lm);
+                sh_touch[lm] = 1;
             }
             __syncthreads();
             double k0 = 0.0, k1 = 0.0;
@@ -501,8 +530,11 @@ __global__ __launch_bounds__(THREADS) void k_pool_run_known(PoolView pv, const d
             }
             __syncthreads();
             if (r < N) {
-                double* row = S + r * ldS;
-                for (int c = 0; c < N; c++) row[c] = row[c] - (k0 * Gg[c] + k1 * Gg[N + c]);  // :191-192
+                double* __restrict__ row = S + r * ldS;
+                const double* __restrict__ G0 = Gg;
+                const double* __restrict__ G1 = Gg + N;
+#pragma unroll 4
+                for (int c = 0; c < N; c++) row[c] = row[c] - (k0 * G0[c] + k1 * G1[c]);  // :191-192
                 double s = st[r] + (k0 * sh_nu[0] + k1 * sh_nu[1]);                             // :186
                 if (r == 0) s = normalize_angle(s);                                             // :187
                 st[r] = s;
@@ -514,6 +546,7 @@ __global__ __launch_bounds__(THREADS) void k_pool_run_known(PoolView pv, const d
     for (int r = tid >> 6; r < N; r += THREADS / 64)
         for (int c = tid & 63; c < N; c += 64) Sg[(size_t)r * ld + c] = S[r * ldS + c];
     for (int r = tid; r < N; r += THREADS) stg[r] = st[r];
+    flush_touches(pv, b, sh_touch, n, THREADS);
 }
 
 size_t small_lds_bytes(int N) { return sizeof(double) * ((size_t)N * (N | 1) + 3 * (size_t)N); }
