@@ -352,8 +352,10 @@ __device__ __forceinline__ void st2(double2_t* p, double2_t v) {
     else *p = v;
 }
 
-template <int U, bool NT>
-__global__ __launch_bounds__(256) void k_rank2(double* __restrict__ sigma, const double* __restrict__ Kg_all,
+// TPB: 256 lanes per strip, or 64 / 128 / 192 when the active row is shorter than that (a narrow map, or a
+// discovered prefix): the waves of a workgroup share nothing, so a narrower workgroup only sheds idle wavefronts.
+template <int U, bool NT, int TPB>
+__global__ __launch_bounds__(TPB) void k_rank2(double* __restrict__ sigma, const double* __restrict__ Kg_all,
                                                const double* __restrict__ Gh_all, const CorrRec* __restrict__ rec,
                                                double* __restrict__ state, int N_launch, int ld,
                                                size_t sigma_stride, int rows_per_block) {
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void k_rank2(double* __restrict__ sigma, const
     const int N = na > 0 ? min(na, N_launch) : N_launch;
     const int ld2n = ld >> 1;
     const int ld2a = (N + 1) >> 1;  // double2 columns that hold an active column
-    const int c2 = blockIdx.x * 256 + threadIdx.x;
+    const int c2 = blockIdx.x * TPB + threadIdx.x;
     const double2_t* __restrict__ Kg = reinterpret_cast<const double2_t*>(Kg_all + (size_t)b * 2 * ld);
     const int row_begin = blockIdx.y * rows_per_block;
     const int row_end = min(N, row_begin + rows_per_block);
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) void k_rank2(double* __restrict__ sigma, const
     if (blockIdx.x == 0) {
         const CorrRec rc = rec[b];
         double* st = state + (size_t)b * ld;
-        for (int rr = row_begin + (int)threadIdx.x; rr < row_end; rr += 256) {
+        for (int rr = row_begin + (int)threadIdx.x; rr < row_end; rr += TPB) {
             const double2_t k = Kg[rr];
             double s = st[rr] + (k.x * rc.nu0 + k.y * rc.nu1);
             if (rr == 0) s = normalize_angle(s);
@@ -724,16 +726,25 @@ void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s) {
     hipLaunchKernelGGL(k_gain, dim3((cover + 255) / 256, pv.B), dim3(256), 0, s, pv, src);
 }
 
-template <int U>
-static void launch_rank2_u(const PoolView& pv, int rows, bool nt, hipStream_t s) {
+template <int U, int TPB>
+static void launch_rank2_ut(const PoolView& pv, int rows, bool nt, hipStream_t s) {
     const int ld2a = (pv.N + 1) / 2;
-    dim3 grid((ld2a + 255) / 256, (pv.N + rows - 1) / rows, pv.B);
+    dim3 grid((ld2a + TPB - 1) / TPB, (pv.N + rows - 1) / rows, pv.B);
     if (nt)
-        hipLaunchKernelGGL((k_rank2<U, true>), grid, dim3(256), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
+        hipLaunchKernelGGL((k_rank2<U, true, TPB>), grid, dim3(TPB), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
                            pv.N, pv.ld, pv.sigma_stride, rows);
     else
-        hipLaunchKernelGGL((k_rank2<U, false>), grid, dim3(256), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
+        hipLaunchKernelGGL((k_rank2<U, false, TPB>), grid, dim3(TPB), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
                            pv.N, pv.ld, pv.sigma_stride, rows);
+}
+
+template <int U>
+static void launch_rank2_u(const PoolView& pv, int rows, bool nt, hipStream_t s) {
+    const int ld2a = (pv.N + 1) / 2;  // double2 columns of an active row
+    if (ld2a <= 64) launch_rank2_ut<U, 64>(pv, rows, nt, s);
+    else if (ld2a <= 128) launch_rank2_ut<U, 128>(pv, rows, nt, s);
+    else if (ld2a <= 192) launch_rank2_ut<U, 192>(pv, rows, nt, s);
+    else launch_rank2_ut<U, 256>(pv, rows, nt, s);
 }
 
 void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s) {
