@@ -229,7 +229,7 @@ def main():
                        "hbm_bytes_per_gpu": bt.device_bytes()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ekf::k_rank2<16,true> (Sigma -= K*(H*Sigma), ekf_slam.cpp:191-192)",
+                         "kernel": "ekf::k_rank2<16,true,256> (Sigma -= K*(H*Sigma), ekf_slam.cpp:191-192)",
                          "algorithmic_bytes_per_launch": st["rank2_bytes_per_launch"],
                          "avg_launch_ms": r2_avg_s * 1e3, "launches": st["rank2_launches"],
                          "rank2_share_of_step_time": st["rank2_ms"] / st["elapsed_ms"]},
