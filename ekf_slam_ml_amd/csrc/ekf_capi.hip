@@ -99,8 +99,8 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     Pool& P = h->pool;
     EKFC(P.use(false));
     const int n = P.pv.n;
-    const bool small = P.small_path && P.pend_cap == 0 && P.pv.N <= ekf::small_max_dim() && n > 0;
-    if (small && n <= ekf::kSmallInlineN) {
+    static_assert(3 + 2 * ekf::kSmallInlineN >= 103, "every map of the small path (odd N <= 104) fits the by-value argument");
+    if (P.small_path && P.pend_cap == 0 && P.pv.N <= ekf::small_max_dim() && n > 0) {
         // small map (the reference runs n = 20): the whole call -- and the prediction() before it -- in one
         // LDS-resident launch whose inputs travel by value in the kernel arguments (no staging, no copy)
         P.alt_synced = false;
@@ -117,18 +117,6 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
         return checked_launch();
     }
     EKFC(P.upload2(P.sensor_dev, sensor_xy, sizeof(double) * 2 * n, visible, (size_t)n));
-    if (small) {
-        P.alt_synced = false;
-        ekf::launch_small_measure(P.pv, P.sensor_dev, P.visible_dev, !P.init_flag, P.pred_pending, P.pred_dth, P.pred_dx,
-                                  P.stream);
-        P.pred_pending = false;
-        P.init_flag = 1;
-        for (int i = n - 1; i >= 0; i--)
-            if (visible[i]) { if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1; break; }
-        for (int i = 0; i < n; i++)
-            if (visible[i]) P.note_touched(i);
-        return checked_launch();
-    }
     EKFC(P.use());  // settles a deferred prediction()
     // ekf_slam.cpp:109-128.  The pose capture needs its own launch only together with the first-call
     // landmark initialisation; afterwards the first correction of the call records the pose it reads

@@ -253,11 +253,10 @@ void launch_circles(const double* ranges, int S, int nb, int max_out, double* ce
                     double* all_out, int* n_clusters, hipStream_t s);
 int circles_max_beams();
 int circles_max_clusters();
-// whole measurement() call of a SMALL map in one single-workgroup, LDS-resident launch (ekf_small.hip)
-void launch_small_measure(const PoolView& pv, const double* sensor, const unsigned char* visible, int do_init,
-                          int has_twist, double dtheta, double dx, hipStream_t s);
-// The same for ONE filter with the inputs passed BY VALUE in the kernel-argument segment (n <= kSmallInlineN):
+// whole measurement() call of a SMALL map (one filter) in one single-workgroup, LDS-resident launch (ekf_small.hip),
+// the inputs passed BY VALUE in the kernel-argument segment (n <= kSmallInlineN covers every N <= small_max_dim()):
 // no staging buffer, no host-to-device copy, no copy -> kernel dependency in the stream.
+// (has_twist: a prediction(dtheta, dx) deferred by the host runs first, on the LDS image)
 constexpr int kSmallInlineN = 50;
 struct SmallInline {
     double sensor[2 * kSmallInlineN];
@@ -269,7 +268,6 @@ constexpr int kSmallInlineJ = 32;
 struct SmallInlineMeas { double xy[2 * kSmallInlineJ]; };  // the measures vector of data_association(), by value
 void launch_small_associate_inline(const PoolView& pv, const SmallInlineMeas& in, int J, int known_count, int* assoc_out,
                                    int has_twist, double dtheta, double dx, hipStream_t s);
-// (has_twist: a prediction(dtheta, dx) deferred by the host runs first, on the LDS image)
 void launch_small_associate(const PoolView& pv, const double* meas, int J, int known_count, int* assoc_out,
                             int has_twist, double dtheta, double dx, hipStream_t s);
 // one step of an unknown-association log for a pool whose every discovered prefix fits the small path:

@@ -1,5 +1,5 @@
 // ekf_small.hip -- LDS-resident kernels for small maps and small discovered prefixes:
-//   k_small_measure     one measurement() call of one filter                       (single-filter API)
+//   k_small_measure_inline  one prediction() + measurement() tick of one filter, inputs by value (single-filter API)
 //   k_small_associate   one data_association() call of one filter                  (single-filter API)
 //   k_pool_associate    one STEP of data_association() for every filter of a pool  (ekf_batch_run_unknown)
 //   k_pool_run_known    a whole RUN of prediction() + measurement() per filter     (ekf_batch_run_known)
@@ -196,16 +196,6 @@ __device__ __forceinline__ void small_measure_body(const PoolView& pv, int b, co
         for (int c = tid & 63; c < N; c += 64) Sg[(size_t)r * ld + c] = S[r * ldS + c];
     for (int r = tid; r < N; r += THREADS) stg[r] = st[r];
     flush_touches(pv, b, sh_touch, n, THREADS);
-}
-
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_small_measure(PoolView pv, const double* __restrict__ sensor,
-                                                           const unsigned char* __restrict__ visible, int do_init,
-                                                           int has_twist, double dtheta, double dx) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int b = blockIdx.x;
-    small_measure_body<THREADS>(pv, b, sensor + (size_t)b * 2 * pv.n, visible + (size_t)b * pv.n, do_init, has_twist,
-                                dtheta, dx, sm);
 }
 
 // One filter, inputs by value: `in` lives in the kernel-argument segment the launch packet already carries.
@@ -421,7 +411,7 @@ __global__ __launch_bounds__(THREADS) void k_pool_associate(PoolView pv, const d
 // A whole RANGE OF STEPS of a known-association log for a pool of small maps in ONE launch: workgroup b keeps
 // filter b's Sigma and state in LDS from the first to the last step -- prediction() (ekf_slam.cpp:55-106, the
 // structured arithmetic of k_predict), the top of measurement() (:109-128) and every logged correction
-// (:132-194, the arithmetic of k_small_measure) -- so HBM sees the log once and Sigma twice per run instead of
+// (:132-194, the arithmetic of k_small_measure_inline) -- so HBM sees the log once and Sigma twice per run instead of
 // (2 + 2V) launches per step.  This is the reference's own operating point (n = 20) at Monte-Carlo scale.
 // Bit-identical to the multi-kernel replay.  The next step's log slots are fetched while the current step runs.
 // ---------------------------------------------------------------------------------------------
@@ -554,9 +544,7 @@ int small_max_dim() { return 104; }  // N <= 104: 87 KB of LDS, one lane per row
 
 hipError_t small_prepare() {
     hipError_t e = hipSuccess;
-    for (const void* f : {reinterpret_cast<const void*>(&k_small_measure<64>),
-                          reinterpret_cast<const void*>(&k_small_measure<128>),
-                          reinterpret_cast<const void*>(&k_small_measure_inline<64>),
+    for (const void* f : {reinterpret_cast<const void*>(&k_small_measure_inline<64>),
                           reinterpret_cast<const void*>(&k_small_measure_inline<128>),
                           reinterpret_cast<const void*>(&k_small_associate_inline<64>),
                           reinterpret_cast<const void*>(&k_small_associate_inline<128>),
@@ -626,16 +614,6 @@ void launch_small_measure_inline(const PoolView& pv, const SmallInline& in, int 
     else
         hipLaunchKernelGGL(k_small_measure_inline<128>, dim3(1), dim3(128), small_lds_bytes(pv.N), s, pv, in, do_init,
                            has_twist, dtheta, dx);
-}
-
-void launch_small_measure(const PoolView& pv, const double* sensor, const unsigned char* visible, int do_init,
-                          int has_twist, double dtheta, double dx, hipStream_t s) {
-    if (pv.N <= 64)
-        hipLaunchKernelGGL(k_small_measure<64>, dim3(pv.B), dim3(64), small_lds_bytes(pv.N), s, pv, sensor, visible, do_init,
-                           has_twist, dtheta, dx);
-    else
-        hipLaunchKernelGGL(k_small_measure<128>, dim3(pv.B), dim3(128), small_lds_bytes(pv.N), s, pv, sensor, visible,
-                           do_init, has_twist, dtheta, dx);
 }
 
 }  // namespace ekf
