@@ -9,12 +9,21 @@ ekf_slam.cpp:137-192); filter steps/s are reported next to it.  Inputs (twists, 
 before the timed region.  Multi-GPU: one process per GPU, filters sharded by global id, no data-path
 collective; RCCL carries only the final throughput reduction ("scaling": "weak").
 
+The same JSON line carries, as separately reported sub-objects (never mixed into `value` / `roofline`):
+  delayed_update, active_set_update, unknown_association (+ its full-map variant), small_map_monte_carlo,
+  and at N = 1 the other BASELINE.json configurations, each with its own roofline and CPU baseline:
+  configs_1 (single filter n = 200 known, through the C ABI), configs_2 (single filter n = 1000 unknown),
+  configs_3 (dense F Sigma F^T + Q, N = 10003, fp32 MFMA).
+
   python bench.py [--gpus N] [--steps K] [--warmup W] [--filters B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+(`python bench.py --gpus N` with N > 1 outside torchrun starts that launcher as a child process itself.)
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,7 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+MFMA_F32_PEAK_TF = 157.3   # same guide: FP32 matrix peak (v_mfma_f32_32x32x2_f32), dense
+RANK2_SOURCE = os.path.join(ROOT, "ekf_slam_ml_amd", "csrc", "ekf_kernels.hip")
 
 
 def parse():
@@ -37,13 +48,45 @@ def parse():
     ap.add_argument("--delayed-k", type=int, default=32,
                     help="also time the delayed rank-2k update with this many corrections per flush (0 = skip)")
     ap.add_argument("--no-active-set", action="store_true", help="skip the active-set leg")
-    ap.add_argument("--no-unknown", action="store_true", help="skip the batched unknown-association leg")
+    ap.add_argument("--no-unknown", action="store_true", help="skip the batched unknown-association legs")
     ap.add_argument("--no-small", action="store_true", help="skip the small-map (n = 20) Monte-Carlo leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs[1..3] legs (single filters, dense)")
+    ap.add_argument("--only-main", action="store_true", help="the contract leg only (profiling runs)")
     ap.add_argument("--host-log", action="store_true",
                     help="generate the synthetic log on the host (numpy) and upload it, instead of on the device")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.only_main:
+        a.no_active_set = a.no_unknown = a.no_small = a.no_configs = True
+        a.delayed_k = 0
+    return a
+
+
+def sha256_of(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
+def pmc_traffic(kernel, B, n):
+    """HBM bytes per launch of the dominant kernel from the committed PMC record (profiles/rank2_traffic.json), or
+    None when that record was taken on a different kernel instantiation, another build of its source file, or another
+    pool shape -- a stale figure is never quoted."""
+    tfile = os.path.join(ROOT, "profiles", "rank2_traffic.json")
+    try:
+        tj = json.load(open(tfile))
+    except (OSError, ValueError):
+        return None, "no profiles/rank2_traffic.json"
+    name = "".join(str(tj.get("kernel", "")).split())
+    if "".join(kernel.split()) not in name:
+        return None, f"PMC record is for {tj.get('kernel')!r}, this run launches {kernel}"
+    if tj.get("source_sha256") != sha256_of(RANK2_SOURCE):
+        return None, "PMC record was taken on another build of ekf_kernels.hip"
+    if tj.get("filters") != B or tj.get("n") != n:
+        return None, "PMC record was taken on another pool shape"
+    return tj.get("hbm_bytes_per_launch"), None
 
 
 def cpu_baseline(sub, K, t_warm, cores, gpu_state):
@@ -62,11 +105,266 @@ def cpu_baseline(sub, K, t_warm, cores, gpu_state):
             "max_abs_state_diff_vs_gpu": float(np.abs(st - gpu_state).max())}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1]: one filter, n = 200, known association, through the C ABI (the node's call sequence:
+# prediction(twist) + measurement(sensor_reading, visible_list) per 10 Hz tick; slam.cpp:433-434).
+# ------------------------------------------------------------------------------------------------------------------
+def leg_configs_1(device, cores, steps=2000, warm=100, want_cpu=True):
+    import numpy as np
+    from ekf_slam_ml_amd import capi, synth
+    cfg = synth.config2(steps=steps)
+    log = synth.make_known_log(cfg)
+    n, N = cfg.n, 3 + 2 * cfg.n
+    inputs = [log.expand_step(t) for t in range(steps)]
+    bytes_corr = 16.0 * N * N
+
+    def run(profile):
+        f = capi.EKF_SLAM(n, device=device)
+        for t in range(warm):
+            f.prediction(log.twist[t, 0]); f.measurement(*inputs[t])
+        f.set_profiling(profile)
+        f.sync()
+        t0 = time.perf_counter()
+        for t in range(warm, steps):
+            f.prediction(log.twist[t, 0]); f.measurement(*inputs[t])
+        f.sync()
+        dt = time.perf_counter() - t0
+        prof = f.profile() if profile else None
+        st = f.state
+        f.close()
+        return dt, prof, st
+
+    dt, _, st_gpu = run(False)
+    _, prof, _ = run(True)
+    corr = int((log.lm_idx[warm:] >= 0).sum())
+    out = {"workload": f"BASELINE.json configs[1]: 1 filter, n={n} (N={N}), known association, {steps - warm} timed steps "
+                       f"after {warm} warm-up, one ekf_predict + ekf_measure_known per step through the C ABI (ctypes loop)",
+           "value": corr / dt, "unit": "update steps/s (landmark corrections)", "filter_steps_per_s": (steps - warm) / dt,
+           "corrections_per_step": corr / (steps - warm), "us_per_correction": dt / corr * 1e6}
+    kern_us = prof["stream_ms"] / max(prof["stream_launches"], 1) * 1e3
+    out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                       "achieved": corr / dt * bytes_corr / 1e9, "frac": corr / dt * bytes_corr / 1e9 / HBM_PEAK_GBS,
+                       "traffic": None, "algorithmic_bytes_per_correction": bytes_corr,
+                       "kernel_avg_us": kern_us, "kernel_launches": prof["stream_launches"],
+                       "corrections_per_launch": corr / max(prof["stream_launches"], 1),
+                       "in_kernel_GBps": bytes_corr * corr / max(prof["stream_launches"], 1) / (kern_us * 1e-6) / 1e9,
+                       "note": "Sigma = 1.3 MB lives in L2: latency-bound, not bandwidth-bound; `achieved` is end to "
+                               "end (corrections/s x 16 N^2 B), kernel_avg_us from HIP events around every "
+                               "covariance-streaming launch in a second, instrumented pass"}
+    if want_cpu:
+        from oracle import binding as ob  # checker / baseline only
+        o = ob.OracleEKF(n, ob.STRUCTURED, fast=True)
+        t0 = time.perf_counter()
+        for t in range(steps):
+            o.prediction(*log.twist[t, 0]); o.measurement(*inputs[t])
+        cdt = time.perf_counter() - t0
+        call = int((log.lm_idx >= 0).sum())
+        od = ob.OracleEKF(n, ob.DENSE, fast=True)
+        dsteps = 6
+        t0 = time.perf_counter()
+        for t in range(dsteps):
+            od.prediction(*log.twist[t, 0]); od.measurement(*inputs[t])
+        ddt = time.perf_counter() - t0
+        dcorr = int((log.lm_idx[:dsteps] >= 0).sum())
+        out["cpu_baseline"] = {"value": call / cdt, "unit": "update steps/s", "cores": 1, "kind": "port",
+                               "sample": f"the same {steps} steps ({call} corrections, {cdt:.2f} s) on the structured "
+                                         f"O(N^2) C restatement, one thread (a single filter is sequential)",
+                               "reference_algorithm_dense": {
+                                   "value": dcorr / max(ddt, 1e-9), "unit": "update steps/s", "cores": 1,
+                                   "sample": f"first {dsteps} steps ({dcorr} corrections, {ddt:.1f} s) of the dense-literal "
+                                             f"restatement = the reference's O(N^3) Armadillo expressions as plain loops "
+                                             f"(no BLAS in the image's C toolchain)"},
+                               "max_abs_state_diff_vs_gpu": float(np.abs(o.state - st_gpu).max())}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2]: one filter, n = 1000, unknown association (prediction + data_association per tick;
+# unknown_data_assoc.cpp:414-415).  (a) the discovery run as SURVEY 8(d) specifies it (M grows from 0);
+# (b) the same sensing against a FULLY discovered map (M = 1000 from the first measurement): every measurement is
+# scored against all 1000 landmarks (ekf_slam.cpp:300-309) and the winner corrected at full width (:331-390).
+# ------------------------------------------------------------------------------------------------------------------
+def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
+    import numpy as np
+    from ekf_slam_ml_amd import capi, synth
+    cfg = synth.config3(steps=steps)
+    log = synth.make_unknown_log(cfg)
+    n, N = cfg.n, 3 + 2 * cfg.n
+    meas = [log.meas_xy[t, 0, :log.count[t, 0]] for t in range(steps)]
+    out = {"workload": f"BASELINE.json configs[2]: 1 filter, n={n} (N={N}), unknown association, J<=8 shuffled readings per "
+                       f"step, one ekf_predict + ekf_associate per step through the C ABI (ctypes loop)"}
+
+    # (a) discovery run
+    warm = 50
+    f = capi.EKF_SLAM(n, device=device)
+    known = np.zeros(n, dtype=np.uint8)
+    for t in range(warm):
+        f.prediction(log.twist[t, 0]); f.data_association(meas[t], known)
+    f.sync()
+    t0 = time.perf_counter()
+    nm = nc = 0
+    scores = 0
+    for t in range(warm, steps):
+        kc = int(known.sum())
+        f.prediction(log.twist[t, 0]); a = f.data_association(meas[t], known)
+        nm += len(a); nc += int((a >= 0).sum())
+        scores += len(a) * kc  # lower bound (known_count grows inside the call)
+    f.sync()
+    dt = time.perf_counter() - t0
+    out["discovery"] = {"value": (steps - warm) / dt, "unit": "filter steps/s", "measurements_per_s": nm / dt,
+                        "corrections_per_s": nc / dt, "scores_per_s": scores / dt, "known_landmarks_end": int(known.sum()),
+                        "steps": steps - warm}
+    f.close()
+
+    # (b) full map: phase A builds the map through the known-association API (first call initialises all n landmarks,
+    # second call corrects all n at full width), phase B is data_association with known_list all true.
+    rng = np.random.default_rng(33)
+    world = log.world
+    pose0 = np.zeros(3)
+
+    def all_readings():
+        rel = synth._robot_frame(world, pose0)
+        return (rel + rng.normal(0.0, cfg.sensor_std, size=rel.shape)).reshape(-1)
+
+    def build(profile):
+        g = capi.EKF_SLAM(n, device=device)
+        g.measurement(all_readings(), np.zeros(n, dtype=np.uint8))
+        g.measurement(all_readings(), np.ones(n, dtype=np.uint8))
+        g.set_profiling(profile)
+        g.sync()
+        return g
+
+    rng = np.random.default_rng(33); g = build(False)
+    snap_state, snap_cov = (g.state, g.cov) if want_cpu else (None, None)
+    kn = np.ones(n, dtype=np.uint8)
+    t0 = time.perf_counter()
+    nm = nc = 0
+    for t in range(full_steps):
+        g.prediction(log.twist[t, 0]); a = g.data_association(meas[t], kn)
+        nm += len(a); nc += int((a >= 0).sum())
+    g.sync()
+    dt = time.perf_counter() - t0
+    st_gpu = g.state
+    g.close()
+    rng = np.random.default_rng(33); g = build(True)
+    for t in range(full_steps):
+        g.prediction(log.twist[t, 0]); g.data_association(meas[t], kn)
+    prof = g.profile()
+    g.close()
+    bytes_corr = 16.0 * N * N
+    k_us = prof["stream_ms"] / max(prof["stream_launches"], 1) * 1e3
+    s_us = prof["score_ms"] / max(prof["score_launches"], 1) * 1e3
+    out["full_map"] = {"value": nm / dt, "unit": "measurements/s (each scored against all 1000 landmarks)",
+                       "filter_steps_per_s": full_steps / dt, "scores_per_s": nm * n / dt, "corrections_per_s": nc / dt,
+                       "known_landmarks": n, "measurements": nm, "corrections": nc, "steps": full_steps,
+                       "score_kernel_avg_us": s_us, "score_launches": prof["score_launches"],
+                       "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                    "achieved": nc / dt * bytes_corr / 1e9, "frac": nc / dt * bytes_corr / 1e9 / HBM_PEAK_GBS,
+                                    "traffic": None, "algorithmic_bytes_per_correction": bytes_corr,
+                                    "kernel_avg_us": k_us, "kernel_launches": prof["stream_launches"],
+                                    "in_kernel_GBps": bytes_corr / (k_us * 1e-6) / 1e9,
+                                    "note": "one decision + full-width correction launch per measurement; Sigma = 32 MB "
+                                            "is served by the Infinity Cache between launches; `achieved` is end to end"}}
+    if want_cpu:
+        from oracle import binding as ob  # checker / baseline only
+        o = ob.OracleEKF(n, ob.STRUCTURED, fast=True)
+        o.state, o.cov = snap_state, snap_cov
+        o.set_init_flag(1)
+        ko = np.ones(n, dtype=np.uint8)
+        csteps = min(full_steps, 60)
+        t0 = time.perf_counter()
+        cm = 0
+        for t in range(csteps):
+            o.prediction(*log.twist[t, 0]); b = o.data_association(meas[t], ko)
+            cm += len(b)
+        cdt = time.perf_counter() - t0
+        out["full_map"]["cpu_baseline"] = {
+            "value": cm / cdt, "unit": "measurements/s", "cores": 1, "kind": "port",
+            "sample": f"first {csteps} steps ({cm} measurements x {n} scores + corrections, {cdt:.1f} s) from the GPU filter's "
+                      f"post-mapping state on the structured C restatement (O(1) per score, O(N^2) per correction), one "
+                      f"thread; the reference scores with a dense 2xN x NxN product per pair (ekf_slam.cpp:267)"}
+        if csteps == full_steps:
+            out["full_map"]["cpu_baseline"]["max_abs_state_diff_vs_gpu"] = float(np.abs(o.state - st_gpu).max())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3]: dense general-F propagation Sigma <- F Sigma F^T + Q, n = 5000 (N = 10003), fp32 MFMA.
+# ------------------------------------------------------------------------------------------------------------------
+def leg_configs_3(device, cores, N=10003, iters=5, want_cpu=True):
+    import numpy as np
+    from ekf_slam_ml_amd import capi
+    rng = np.random.default_rng(4)
+    F = np.eye(N, dtype=np.float32) + rng.standard_normal((N, N), dtype=np.float32) * np.float32(0.05 / np.sqrt(N))
+    A = rng.standard_normal((N, 64), dtype=np.float32)
+    S = A @ A.T / np.float32(64) + np.eye(N, dtype=np.float32)
+    Q = np.zeros((N, N), dtype=np.float32)
+    Q[0, 0] = Q[1, 1] = Q[2, 2] = 1e-4
+    d = capi.DensePropagator(N, device=device)
+    info = d.launch_info()
+    d.set(F, S, Q)
+    d.propagate(1)  # warm-up + the result that is checked
+    got = d.sigma
+    rows = np.array(sorted({0, 2, N // 2, N - 1, *[int(x) for x in rng.integers(0, N, size=4)]}))
+    F64 = F.astype(np.float64)
+    want = (F64[rows] @ S.astype(np.float64)) @ F64.T + Q[rows].astype(np.float64)
+    err = float(np.abs(got[rows] - want).max() / np.abs(want).max())
+    d.set(F, S, Q)
+    ms = [d.propagate(1) for _ in range(iters)]
+    d.close()
+    med = float(np.median(ms))
+    flop = 4.0 * float(N) ** 3
+    tf = flop / (med * 1e-3) / 1e12
+    out = {"workload": f"BASELINE.json configs[3]: Sigma <- F Sigma F^T + Q, dense random F, N={N} (n=5000), fp32 on "
+                       f"v_mfma_f32_32x32x2_f32, two products per propagation (ekf_slam.cpp:101-102)",
+           "value": 1e3 / med, "unit": "propagations/s", "ms_per_propagation": med, "dtype": "f32",
+           "launch": info, "fp64_check_rel_err": err, "fp64_check_rows": [int(r) for r in rows],
+           "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF, "achieved": tf,
+                        "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "algorithmic_flop_per_propagation": flop,
+                        "avg_launch_ms": med / 2.0,
+                        "note": "HIP events around the two products of one propagation (main kernel + quarter-tile tail "
+                                "kernel on a second stream); median of the timed propagations"}}
+    if want_cpu:
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:
+            threadpool_limits = None
+        Nc = 3072
+        Fc, Sc = np.ascontiguousarray(F[:Nc, :Nc]), np.ascontiguousarray(S[:Nc, :Nc])
+
+        def prod():
+            return (Fc @ Sc) @ Fc.T + Q[:Nc, :Nc]
+        import contextlib
+        with (threadpool_limits(limits=cores) if threadpool_limits else contextlib.nullcontext()):
+            prod()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                prod()
+            cdt = (time.perf_counter() - t0) / reps
+        ctf = 4.0 * Nc ** 3 / cdt / 1e12
+        out["cpu_baseline"] = {"value": ctf * 1e12 / flop, "unit": "propagations/s (scaled from the sample by flop count)",
+                               "cores": cores, "kind": "port", "tflops": ctf,
+                               "sample": f"fp32 F Sigma F^T + Q at N={Nc} ({4.0 * Nc ** 3 / 1e9:.0f} GFLOP, {cdt:.2f} s) as two "
+                                         f"numpy/OpenBLAS sgemm calls on {cores} threads -- what Armadillo's operator* "
+                                         f"resolves to with a BLAS back end"}
+    return out
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the one-process-per-GPU launcher as a CHILD (nothing has touched the GPU
+        # yet in this process; never an exec after GPU initialisation) and exit with its code
+        port = str(29500 + os.getpid() % 1000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); pass --gpus {world}")
     dist = None
     import numpy as np
     # torch first: it bundles its own libamdhip64.so.7 and libekfslam_hip.so must share that runtime
@@ -96,7 +394,13 @@ def main():
     B = a.filters if a.filters > 0 else 4096
     B = max(1, min(B, int(0.90 * free // per_filter), 65535))
     K, W = a.steps, a.warmup
-    T = W + K + 1  # step 0 = first measurement() call (landmark initialisation, no corrections)
+    # The delayed leg times whole flushes only: its step count Kd is K rounded up until the 2*Kd corrections per filter
+    # are a multiple of the k corrections per flush (a trailing near-empty flush would dilute the figure).
+    Kd = K
+    if a.delayed_k > 0:
+        while (2 * Kd) % a.delayed_k:
+            Kd += 1
+    T = W + max(K, Kd) + 1  # step 0 = first measurement() call (landmark initialisation, no corrections)
 
     from ekf_slam_ml_amd import shard
     first_id, count = shard.shard(B * world, world, rank)  # weak scaling: B filters per GPU, global ids
@@ -130,11 +434,18 @@ def main():
 
     corr = float(st["corrections"])
     fsteps = float(st["filter_steps"])
-    # the only collective of the job: RCCL all-reduce of three scalars (max wall, summed work)
+    # the only collective of the job: RCCL all-reduce of a few scalars (max wall, summed work, ranks seen)
     wall, corr, fsteps = shard.reduce_throughput(wall, corr, fsteps, device=red_dev)
-    eager_state = [bt.state(b) for b in range(min(B, 4))] if rank == 0 else None
+    ranks_seen = shard.count_ranks(device=red_dev)
+    cores = int(os.environ.get("EKF_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+    want_cpu = world == 1 and not a.no_cpu_baseline
+    # the eager leg's own end states: the CPU baseline's parity spot-check and the other legs compare against THESE
+    Bc = a.cpu_filters if a.cpu_filters > 0 else min(B, 160 * cores)
+    eager_state = None
+    if rank == 0:
+        eager_state = np.stack([bt.state(b) for b in range(Bc if want_cpu else min(B, 4))])
 
-    # Second, separately reported leg: the SAME K steps with the delayed
+    # Second, separately reported leg: the same log with the delayed
     # rank-2k covariance update.  Its traffic is different by construction, so it has its own declared
     # bytes and never enters `value` / `roofline` above.
     delayed = None
@@ -144,7 +455,7 @@ def main():
         bt.run_known(0, 1 + W)
         fence()
         t0 = time.perf_counter()
-        sd = bt.run_known(1 + W, 1 + W + K, time_kernels=True)
+        sd = bt.run_known(1 + W, 1 + W + Kd, time_kernels=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         fence()
@@ -156,18 +467,19 @@ def main():
             # declared algorithmic bytes per correction: flush share (Sigma read+write + factor reads) +
             # average factor read of the gain step + base gathers + factor/state append
             per_corr = (16.0 * Nf * Nf + 32.0 * Nf * kk) / kk + 16.0 * Nf * (kk - 1.0) + 14.0 * 8.0 * Nf
-            dstate = [bt.state(b) for b in range(min(B, 4))]
             delayed = {"value": dcorr / dwall, "unit": "update steps/s", "corrections_per_flush": a.delayed_k,
-                       "ms_per_step": dwall / K * 1e3, "flushes": sd["rank2_launches"],
+                       "steps": Kd, "ms_per_step": dwall / Kd * 1e3, "flushes": sd["rank2_launches"],
                        "flush_avg_ms": sd["rank2_ms"] / max(sd["rank2_launches"], 1),
                        "flush_share_of_time": sd["rank2_ms"] / sd["elapsed_ms"],
                        "declared_bytes_per_correction": per_corr,
                        "achieved_GBps_on_declared_bytes": dcorr / world * per_corr / dwall / 1e9,
                        "frac_of_8TBps": dcorr / world * per_corr / dwall / 1e9 / HBM_PEAK_GBS,
                        "speedup_vs_eager": (dcorr / dwall) / (corr / wall),
-                       "max_abs_state_diff_vs_eager": float(max(np.abs(x - y).max() for x, y in zip(dstate, eager_state))),
                        "note": "Sigma = Sigma_base - sum K_j (H Sigma)_j kept as factors, rewritten once per "
                                "k corrections; results equal the eager path to rounding (tests/test_gpu_delayed.py)"}
+            if Kd == K:
+                dstate = np.stack([bt.state(b) for b in range(min(B, 4))])
+                delayed["max_abs_state_diff_vs_eager"] = float(np.abs(dstate - eager_state[:len(dstate)]).max())
         bt.set_update_mode(0)
 
     # Third, separately reported leg: the eager correction restricted to the rows of the TOUCHED set (exact,
@@ -187,14 +499,14 @@ def main():
         awall, acorr, _ = shard.reduce_throughput(t1 - t0, float(sa["corrections"]), float(sa["filter_steps"]),
                                                   device=red_dev)
         if rank == 0:
-            astate = [bt.state(b) for b in range(min(B, 4))]
+            astate = np.stack([bt.state(b) for b in range(min(B, 4))])
             tch = bt.touched()
             active = {"value": acorr / awall, "unit": "update steps/s", "ms_per_step": awall / K * 1e3,
                       "touched_landmarks_mean": float(tch.mean()), "touched_landmarks_max": int(tch.max()),
                       "declared_bytes_per_correction": 16.0 * N * (3 + 2 * float(tch.mean())),
                       "rank2_share_of_time": sa["rank2_ms"] / sa["elapsed_ms"],
                       "speedup_vs_eager": (acorr / awall) / (corr / wall),
-                      "bit_identical_to_eager": bool(all(np.array_equal(x, y) for x, y in zip(astate, eager_state))),
+                      "bit_identical_to_eager": bool(np.array_equal(astate, eager_state[:len(astate)])),
                       "note": "workload-dependent: rows of never-corrected landmarks have K = 0 exactly and are "
                               "skipped (the 2 nearest landmarks of a slowly moving robot stay the same for many "
                               "steps, so few are ever touched here); with every landmark corrected it degenerates "
@@ -205,15 +517,8 @@ def main():
     if rank == 0:
         r2_avg_s = st["rank2_ms"] / max(st["rank2_launches"], 1) * 1e-3
         achieved = st["rank2_bytes_per_launch"] / r2_avg_s / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "rank2_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                if tj.get("filters") == B and tj.get("n") == n:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        kname, krows = bt.rank2_kernel()
+        traffic, why_not = pmc_traffic(kname, B, n)
         out = {
             "metric": "EKF update steps/sec + achieved HBM GB/s vs roofline, n=1000 landmarks",
             "value": corr / wall,
@@ -226,15 +531,17 @@ def main():
                                    f"GPU, n={n} landmarks (N={N}), known association, V=2 corrections per filter step",
                        "filters_per_gpu": B, "landmarks": n, "state_dim": N, "corrections_per_filter_step": 2,
                        "filter_steps_per_s": fsteps / wall, "sharding": f"independent filters x {world} GPUs",
-                       "hbm_bytes_per_gpu": bt.device_bytes()},
+                       "ranks_seen": ranks_seen, "hbm_bytes_per_gpu": bt.device_bytes()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ekf::k_rank2<16,true,256> (Sigma -= K*(H*Sigma), ekf_slam.cpp:191-192)",
+                         "kernel": f"{kname} (Sigma -= K*(H*Sigma), ekf_slam.cpp:191-192), {krows} rows per workgroup",
                          "algorithmic_bytes_per_launch": st["rank2_bytes_per_launch"],
                          "avg_launch_ms": r2_avg_s * 1e3, "launches": st["rank2_launches"],
                          "rank2_share_of_step_time": st["rank2_ms"] / st["elapsed_ms"]},
             "device_elapsed_ms": st["elapsed_ms"],
         }
+        if traffic is None:
+            out["roofline"]["traffic_note"] = why_not
         if delayed is not None:
             out["delayed_update"] = delayed
         if active is not None:
@@ -242,24 +549,22 @@ def main():
         if not a.host_log:
             # Monte-Carlo consistency of the batch against the simulated ground truth (f4)
             out["mc_consistency"] = bt.mc_stats(T - 1)
-        if world == 1 and not a.no_cpu_baseline:
-            # the box's CPU share for a one-GPU job is 16 cores (the machine reports all 256)
-            cores = int(os.environ.get("EKF_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+        if want_cpu:
             # bounded sample: ~10 s of CPU work incl. the untimed warm-up (each filter is 32 MB of covariance: 82 GB)
-            Bc = a.cpu_filters if a.cpu_filters > 0 else min(B, 160 * cores)
             import copy
             cfg_c = copy.copy(cfg)
             cfg_c.filters = Bc
+            cfg_c.steps = 1 + W + K
+            Tc = 1 + W + K
             if log is None:
                 tw, li, zz, ii, _ = bt.download_log(want_truth=False)
-                sub = synth.KnownLog(cfg_c, world_xy, tw[:, :Bc], li[:, :Bc], zz[:, :Bc], ii[:Bc])
+                sub = synth.KnownLog(cfg_c, world_xy, tw[:Tc, :Bc], li[:Tc, :Bc], zz[:Tc, :Bc], ii[:Bc])
             else:
-                sub = synth.KnownLog(cfg_c, log.world, log.twist[:, :Bc], log.lm_idx[:, :Bc], log.z_xy[:, :Bc],
+                sub = synth.KnownLog(cfg_c, log.world, log.twist[:Tc, :Bc], log.lm_idx[:Tc, :Bc], log.z_xy[:Tc, :Bc],
                                      log.init_xy[:Bc])
-            gpu_state = np.stack([bt.state(b) for b in range(Bc)])  # (state after the last leg that ran)
-            out["cpu_baseline"] = cpu_baseline(sub, K, 1 + W, cores, gpu_state)
+            out["cpu_baseline"] = cpu_baseline(sub, K, 1 + W, cores, eager_state[:Bc])
 
-    # Last, separately reported leg: data_association() (a4/a5) over the same pool -- every robot discovers its map
+    # Separately reported leg: data_association() (a4/a5) over the same pool -- every robot discovers its map
     # from shuffled, unlabelled readings generated on the device; scores, gate decisions, landmark initialisation
     # and corrections all stay on the device.  Corrections are exactly confined to each filter's discovered prefix.
     if not a.no_unknown and not a.host_log:
@@ -284,11 +589,14 @@ def main():
                 "value": usteps / uwall, "unit": "filter steps/s (1 step = prediction + data_association of <= 8 readings)",
                 "corrections_per_s": ucorr / uwall, "measurement_slots": su["rank2_launches"],
                 "known_landmarks_min": int(kc.min()), "known_landmarks_max": int(kc.max()),
+                "active_dimension_max": 3 + 2 * int(kc.max()),
                 "rank2_share_of_time": su["rank2_ms"] / su["elapsed_ms"],
                 "mc_consistency": bt.mc_stats(Tu - 1),
-                "note": "configs[2]'s world and sensor for every filter of the pool; landmarks are appended in discovery "
-                        "order, so each filter's corrections stream only its leading 3 + 2*known block (bit-identical "
-                        "to the full-width update, tests/test_gpu_batch_unknown.py)"}
+                "note": f"capacity n = {n}, but after {Tu} steps each filter has discovered only "
+                        f"{int(kc.min())}..{int(kc.max())} landmarks: this leg measures the SMALL discovered-prefix regime "
+                        "(LDS-resident step kernel); landmarks are appended in discovery order, so each filter's "
+                        "corrections stream only its leading 3 + 2*known block (bit-identical to the full-width update, "
+                        "tests/test_gpu_batch_unknown.py).  The large-prefix regime is `unknown_association_large_prefix`"}
     # The reference's own operating point at Monte-Carlo scale: configs[0] (n = 20, 1000 steps) for 8192 robots per
     # GPU, inputs simulated on the device, the whole run ONE launch with every covariance resident in LDS.
     if not a.no_small and not a.host_log:
@@ -315,9 +623,17 @@ def main():
                 "note": "BASELINE.json configs[0] (the reference's n = 20 known-association run) for every filter; "
                         "bit-identical to the per-step replay (tests/test_gpu_pool_small.py)"}
         sb.close()
+    bt.close()
+    # The other BASELINE.json configurations (N = 1 only: they are single-GPU, single-filter workloads).
+    if world == 1 and not a.no_configs:
+        torch.cuda.empty_cache()
+        for key, leg in (("configs_1", leg_configs_1), ("configs_2", leg_configs_2), ("configs_3", leg_configs_3)):
+            try:
+                out[key] = leg(local, cores, want_cpu=want_cpu)
+            except Exception as e:  # a failing side leg must not take the contract line down with it
+                out[key] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    bt.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -40,6 +40,8 @@ SYMBOLS = [
     "ekf_circle_fit_scans", "ekf_normalize_angles",
     "ekf_default_lidar_params", "ekf_batch_simulate_unknown_log", "ekf_batch_download_unknown_log", "ekf_simulate_scans",
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
+    "ekf_dense_launch_info", "ekf_batch_rank2_variant",
+    "ekf_set_profiling", "ekf_get_profile",
 ]
 
 
@@ -174,6 +176,10 @@ def load():
         "ekf_dense_set": [h, _fp, _fp, _fp],
         "ekf_dense_propagate": [h, C.c_int, _dp],
         "ekf_dense_get_sigma": [h, _fp],
+        "ekf_dense_launch_info": [h, _ip, _ip, _ip, _ip],
+        "ekf_batch_rank2_variant": [h, _ip, _ip, _ip, _ip],
+        "ekf_set_profiling": [h, C.c_int],
+        "ekf_get_profile": [h, _dp, C.POINTER(C.c_longlong)],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -332,6 +338,17 @@ class EKF_SLAM:
 
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
+
+    def set_profiling(self, enable=True):
+        """HIP-event timing of every covariance-streaming (class 0) and scoring (class 1) launch; resets the sums"""
+        _check(self._lib.ekf_set_profiling(self._h, int(bool(enable))))
+
+    def profile(self):
+        """{stream_ms, stream_launches, score_ms, score_launches} since set_profiling(True)"""
+        ms = (C.c_double * 2)()
+        ln = (C.c_longlong * 2)()
+        _check(self._lib.ekf_get_profile(self._h, ms, ln))
+        return {"stream_ms": ms[0], "stream_launches": ln[0], "score_ms": ms[1], "score_launches": ln[1]}
 
     def set_update_mode(self, max_pending_corrections=0, symmetric_gather=False):
         """0 = eager covariance stream per correction; k > 0 = delayed rank-2k update (flush every k)."""
@@ -503,6 +520,13 @@ class BatchEKF:
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_batch_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
 
+    def rank2_kernel(self):
+        """name of the k_rank2 instantiation a full-width eager correction of this pool launches, + rows per workgroup"""
+        v = [C.c_int() for _ in range(4)]
+        _check(self._lib.ekf_batch_rank2_variant(self._h, *[C.byref(x) for x in v]))
+        u, nt, tpb, rows = (x.value for x in v)
+        return f"ekf::k_rank2<{u},{'true' if nt else 'false'},{tpb}>", rows
+
     def set_active_set(self, enable=True):
         """Stream only the rows of the touched set in the eager correction (exact; opt-in)."""
         _check(self._lib.ekf_batch_set_active_set(self._h, int(bool(enable))))
@@ -558,6 +582,12 @@ class DensePropagator:
         out = np.empty((self.N, self.N), dtype=np.float32)
         _check(self._lib.ekf_dense_get_sigma(self._h, out.ctypes.data_as(_fp)))
         return out
+
+    def launch_info(self):
+        """{ld, tiles, n_big, n_tail}: how one product is cut into full tiles and quarter-tile tail (test hook)"""
+        v = [C.c_int() for _ in range(4)]
+        _check(self._lib.ekf_dense_launch_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("ld", "tiles", "n_big", "n_tail"), (x.value for x in v)))
 
 
 MAX_CLUSTERS = 128

@@ -228,18 +228,24 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         if (P.fused_ok()) {  // two launches per measurement: scores (+ correction terms), then decision + correction
             EKFC(P.ensure_alt());
             const ekf::MeasSrc msf{mj, 2, nullptr, 0, P.terms};
+            EKFC(P.prof_begin(1));
             ekf::launch_maha(P.pv, msf, P.scores, -1, known_count + j < n ? known_count + j : n, P.stream);
+            EKFC(P.prof_end());
             ekf::PoolView view = P.pv;
             if (active_N > 0 && active_N < P.pv.N) view.N = active_N;
+            EKFC(P.prof_begin(0));
             ekf::launch_associate_fused(view, msf, P.scores, P.assoc_alt, P.assoc_out_dev + j, P.sigma_alt, P.state_fz,
                                         P.stream);
+            EKFC(P.prof_end());
             std::swap(P.pv.sigma, P.sigma_alt);
             std::swap(P.pv.state, P.state_fz);
             std::swap(P.pv.assoc, P.assoc_alt);
             continue;
         }
         const ekf::MeasSrc ms{mj, 2, nullptr, 0};
+        EKFC(P.prof_begin(1));
         ekf::launch_maha(P.pv, ms, P.scores, -1, known_count + j < n ? known_count + j : n, P.stream);  // :300-309
+        EKFC(P.prof_end());
         ekf::launch_assoc_decide(P.pv, ms, P.scores, P.assoc_out_dev, 0, j, nullptr, P.stream);    // :293-330
         src.meas = mj;
         src.meas_stride = 2;
@@ -338,6 +344,26 @@ ekf_status ekf_set_fused_correction(ekf_handle h, int enable) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     h->pool.fused = enable ? 1 : 0;
     h->pool.alt_synced = false;
+    return EKF_OK;
+}
+
+ekf_status ekf_set_profiling(ekf_handle h, int enable) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    Pool& P = h->pool;
+    EKFC(P.use());
+    EKFC(P.prof_drain());
+    P.prof_on = enable ? 1 : 0;
+    P.prof_ms[0] = P.prof_ms[1] = 0.0;
+    P.prof_launches[0] = P.prof_launches[1] = 0;
+    return EKF_OK;
+}
+
+ekf_status ekf_get_profile(ekf_handle h, double ms[2], long long launches[2]) {
+    if (!h || !ms || !launches) return fail(EKF_ERR_INVALID, "null argument");
+    Pool& P = h->pool;
+    EKFC(P.use());
+    EKFC(P.prof_drain());
+    for (int c = 0; c < 2; c++) { ms[c] = P.prof_ms[c]; launches[c] = P.prof_launches[c]; }
     return EKF_OK;
 }
 

@@ -72,6 +72,12 @@ ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int non
     return EKF_OK;
 }
 
+ekf_status ekf_batch_rank2_variant(ekf_batch_handle hb, int* group_rows, int* nontemporal, int* threads, int* rows_per_block) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    ekf::rank2_variant(hb->pool.pv, hb->pool.tuning, group_rows, nontemporal, threads, rows_per_block);
+    return EKF_OK;
+}
+
 ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections, int symmetric_gather) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
     return hb->pool.set_update_mode(max_pending_corrections, symmetric_gather);

@@ -114,6 +114,13 @@ ekf_status ekf_dense_propagate(ekf_dense_handle d, int iterations, double* elaps
     return EKF_OK;
 }
 
+ekf_status ekf_dense_launch_info(ekf_dense_handle d, int* ld, int* tiles, int* n_big, int* n_tail) {
+    if (!d) return fail(EKF_ERR_INVALID, "null handle");
+    if (ld) *ld = d->ld;
+    ekf::dense_gemm_split(d->ld, d->stream2 != nullptr, tiles, n_big, n_tail);
+    return EKF_OK;
+}
+
 ekf_status ekf_dense_get_sigma(ekf_dense_handle d, float* out) {
     if (!d || !out) return fail(EKF_ERR_INVALID, "null argument");
     HIPC(hipSetDevice(d->device));

@@ -232,15 +232,22 @@ hipError_t dense_gemm_prepare() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (a + BK * 128 + 3) * sizeof(float)));
 }
 
-void launch_dense_gemm(const float* A, const float* B, float* C, const float* Qadd, int ld, bool b_transposed,
-                       hipStream_t s, hipStream_t s_tail) {
+void dense_gemm_split(int ld, bool has_tail_stream, int* tiles_out, int* n_big_out, int* n_rem_out) {
     const int tiles = ld / kDenseTile;
     const int total = tiles * tiles;
     // full rounds of resident workgroups run 128 x 128 tiles; the remainder is cut into 64 x 64 quarters
     const int slots = 256 * (g_dense_nbuf == 2 ? 2 : 3);  // resident workgroups: __launch_bounds__ of k_gemm_f32
     int n_big = total / slots * slots;
-    if (total % 8 == 0 || !s_tail || n_big == 0) n_big = total;  // (the XCD remap needs the list in one piece)
-    const int n_rem = total - n_big;
+    if (total % 8 == 0 || !has_tail_stream || n_big == 0) n_big = total;  // (the XCD remap needs the list in one piece)
+    if (tiles_out) *tiles_out = tiles;
+    if (n_big_out) *n_big_out = n_big;
+    if (n_rem_out) *n_rem_out = total - n_big;
+}
+
+void launch_dense_gemm(const float* A, const float* B, float* C, const float* Qadd, int ld, bool b_transposed,
+                       hipStream_t s, hipStream_t s_tail) {
+    int tiles, n_big, n_rem;
+    dense_gemm_split(ld, s_tail != nullptr, &tiles, &n_big, &n_rem);
     const size_t lds = dense_gemm_lds_bytes(b_transposed);
     if (g_dense_nbuf == 2) {
         if (b_transposed) hipLaunchKernelGGL((k_gemm_f32<true, 2>), dim3(n_big), dim3(256), lds, s, A, B, C, Qadd, ld, tiles);

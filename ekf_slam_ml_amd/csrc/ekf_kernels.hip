@@ -747,7 +747,8 @@ static void launch_rank2_u(const PoolView& pv, int rows, bool nt, hipStream_t s)
     else launch_rank2_ut<U, 256>(pv, rows, nt, s);
 }
 
-void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s) {
+// which instantiation of k_rank2 (and how many rows per workgroup) a launch over this view takes
+void rank2_variant(const PoolView& pv, const Rank2Tuning& t, int* u_out, int* nt_out, int* tpb_out, int* rows_out) {
     // Non-temporal only when the pool cannot stay resident in the 256 MiB Infinity Cache between
     // two corrections; a single filter's covariance (32 MB at n = 1000) should stay cached.
     // (the bytes this launch touches: pv.N may be a discovered prefix of a much larger pool)
@@ -765,6 +766,18 @@ void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s) {
     }
     if (rows > 1024) rows = 1024;
     if (u != 2 && u != 4 && u != 8 && u != 16) u = rows >= 32 ? 16 : (rows >= 8 ? 8 : (rows >= 4 ? 4 : 2));
+    const int ld2a = (pv.N + 1) / 2;
+    const int tpb = ld2a <= 64 ? 64 : (ld2a <= 128 ? 128 : (ld2a <= 192 ? 192 : 256));
+    if (u_out) *u_out = u;
+    if (nt_out) *nt_out = nt ? 1 : 0;
+    if (tpb_out) *tpb_out = tpb;
+    if (rows_out) *rows_out = rows;
+}
+
+void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s) {
+    int u, nti, tpb, rows;
+    rank2_variant(pv, t, &u, &nti, &tpb, &rows);
+    const bool nt = nti != 0;
     switch (u) {
         case 2: launch_rank2_u<2>(pv, rows, nt, s); break;
         case 4: launch_rank2_u<4>(pv, rows, nt, s); break;

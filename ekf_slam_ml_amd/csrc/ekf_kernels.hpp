@@ -223,6 +223,8 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
 void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init, hipStream_t s);
 void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s);
 void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s);
+// the k_rank2<U, NT, TPB> instantiation and rows per workgroup launch_rank2 takes for this view (report hook)
+void rank2_variant(const PoolView& pv, const Rank2Tuning& t, int* u, int* nontemporal, int* tpb, int* rows);
 // Same update restricted to the rows of the touched set (exact: every other row has K = 0).
 // max_touched: host-side upper bound of touch_count over the pool (sizes the grid).
 void launch_rank2_active(const PoolView& pv, const Rank2Tuning& t, int max_touched, hipStream_t s);

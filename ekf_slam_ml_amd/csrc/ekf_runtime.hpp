@@ -158,6 +158,48 @@ struct Pool {
     ekf::AssocRec* assoc_alt = nullptr;  // "next" association record of the fused data_association() step
     double* terms = nullptr;             // [n][16] correction terms k_maha leaves for the winner
 
+    // Optional per-launch HIP-event timing of a single filter's kernels (bench.py's configs[1] / configs[2] legs):
+    // class 0 = launches that stream the covariance (fused correction, rank-2, decision + correction),
+    // class 1 = Mahalanobis scoring launches.  Off by default: the events sit on the stream between launches.
+    int prof_on = 0;
+    std::vector<hipEvent_t> prof_ev;   // pairs (begin, end)
+    std::vector<int> prof_cls;
+    size_t prof_used = 0;
+    double prof_ms[2] = {0.0, 0.0};
+    long long prof_launches[2] = {0, 0};
+    static constexpr size_t kProfPairs = 2048;
+    ekf_status prof_drain() {
+        if (prof_used == 0) return EKF_OK;
+        HIPC(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < prof_used; i++) {
+            float m = 0.f;
+            HIPC(hipEventElapsedTime(&m, prof_ev[2 * i], prof_ev[2 * i + 1]));
+            prof_ms[prof_cls[i]] += m;
+            prof_launches[prof_cls[i]]++;
+        }
+        prof_used = 0;
+        return EKF_OK;
+    }
+    ekf_status prof_begin(int cls) {
+        if (!prof_on) return EKF_OK;
+        if (prof_used == kProfPairs) EKFC(prof_drain());
+        while (prof_ev.size() < 2 * (prof_used + 1)) {
+            hipEvent_t e;
+            HIPC(hipEventCreate(&e));
+            prof_ev.push_back(e);
+        }
+        if (prof_cls.size() <= prof_used) prof_cls.resize(prof_used + 1);
+        prof_cls[prof_used] = cls;
+        HIPC(hipEventRecord(prof_ev[2 * prof_used], stream));
+        return EKF_OK;
+    }
+    ekf_status prof_end() {
+        if (!prof_on) return EKF_OK;
+        HIPC(hipEventRecord(prof_ev[2 * prof_used + 1], stream));
+        prof_used++;
+        return EKF_OK;
+    }
+
     bool fused_ok() const { return fused && pv.B == 1 && pend_cap == 0 && !active_set; }
     ekf_status ensure_alt() {
         if (!sigma_alt) {
@@ -225,15 +267,19 @@ struct Pool {
         if (active_N > 0 && active_N < pv.N) view.N = active_N;
         if (fused_ok()) {  // single filter: gain + state + covariance in one launch, out of place
             EKFC(ensure_alt());
+            EKFC(prof_begin(0));
             ekf::launch_correct_fused(view, src, sigma_alt, state_fz, stream);
+            EKFC(prof_end());
             std::swap(pv.sigma, sigma_alt);
             std::swap(pv.state, state_fz);
             return EKF_OK;
         }
         alt_synced = false;
         ekf::launch_gain(view, src, stream);
+        EKFC(prof_begin(0));
         if (active_set && active_N == 0) ekf::launch_rank2_active(pv, tuning, touched_bound, stream);
         else ekf::launch_rank2(view, tuning, stream);
+        EKFC(prof_end());
         return EKF_OK;
     }
 
@@ -364,6 +410,7 @@ struct Pool {
         stage_in.release();
         stage_out.release();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         if (stream) (void)hipStreamDestroy(stream);

@@ -296,8 +296,14 @@ __device__ int small_associate_body(const PoolView& pv, int b, int N, const doub
         }
         __syncthreads();
         const int lm = sh_lm;
-        if (lm < 0) continue;                            // dropped (uniform)
-        if (sh_new) {                                    // :331-381 with the FRESH pose: a new landmark has no record
+        const int is_new = sh_new;
+        if (lm < 0) {                                    // dropped (uniform)
+            // every wave has read sh_lm / sh_new before lane 0 may overwrite them in the next measurement's decision
+            // (128-thread workgroups: wave 0 alone scores and decides, and could run ahead of a slower wave 1)
+            __syncthreads();
+            continue;
+        }
+        if (is_new) {                                    // :331-381 with the FRESH pose: a new landmark has no record
             if (tid == 0) {
                 MeasTerms mn;
                 measurement_terms(st[2 * lm + 3], st[2 * lm + 4], mx, my, st[0], st[1], st[2], mn);

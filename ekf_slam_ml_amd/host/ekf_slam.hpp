@@ -50,15 +50,23 @@ private:
 };
 
 namespace detail {
-// arma::mat exposes memptr()/n_elem; std::vector exposes data()/size().
+// arma::mat exposes memptr()/n_elem AND size() (and, in recent versions, data()-like members); std::vector
+// exposes data()/size() only.  The overloads are RANKED (rank<1> is tried first, rank<0> is its base class)
+// so a type offering both spellings takes the Armadillo one instead of being ambiguous.
+template <int I> struct rank : rank<I - 1> {};
+template <> struct rank<0> {};
 template <class M>
-auto data_of(const M& m) -> decltype(m.memptr()) { return m.memptr(); }
+auto data_of(const M& m, rank<1>) -> decltype(static_cast<const double*>(m.memptr())) { return m.memptr(); }
 template <class M>
-auto data_of(const M& m) -> decltype(m.data()) { return m.data(); }
+auto data_of(const M& m, rank<0>) -> decltype(static_cast<const double*>(m.data())) { return m.data(); }
 template <class M>
-auto size_of(const M& m) -> decltype(static_cast<size_t>(m.n_elem)) { return static_cast<size_t>(m.n_elem); }
+const double* data_of(const M& m) { return data_of(m, rank<1>{}); }
 template <class M>
-auto size_of(const M& m) -> decltype(static_cast<size_t>(m.size())) { return static_cast<size_t>(m.size()); }
+auto size_of(const M& m, rank<1>) -> decltype(static_cast<size_t>(m.n_elem)) { return static_cast<size_t>(m.n_elem); }
+template <class M>
+auto size_of(const M& m, rank<0>) -> decltype(static_cast<size_t>(m.size())) { return static_cast<size_t>(m.size()); }
+template <class M>
+size_t size_of(const M& m) { return size_of(m, rank<1>{}); }
 
 inline void check(ekf_status st, const char* where) {
     if (st != EKF_OK) throw std::runtime_error(std::string(where) + ": " + ekf_last_error());
@@ -122,12 +130,18 @@ public:
     double getStateY() { return pose()[2]; }
     double getStateTheta() { return pose()[0]; }
 
-    /// estimated landmark positions, rows 3..N-1 of the state (ekf_slam.hpp:55-57, ekf_slam.cpp:416-418).
-    /// MatT must be constructible as MatT(rows) or MatT(rows, 1); the default is std::vector<double>.
+    /// estimated landmark positions, rows 3..N-1 of the state (ekf_slam.hpp:55-57, ekf_slam.cpp:416-418)
     std::vector<double> getStateLandmark() {
         std::vector<double> out(static_cast<size_t>(2 * n));
         detail::check(ekf_get_landmarks(handle(), out.data()), "getStateLandmark");
         return out;
+    }
+    /// the same as a 2n x 1 column of a matrix type constructible as MatT(const double* ptr, rows, cols)
+    /// with copy semantics -- arma::mat's auxiliary-memory constructor (what the shim returns to nuslam)
+    template <class MatT>
+    MatT getStateLandmarkAs() {
+        const std::vector<double> v = getStateLandmark();
+        return MatT(v.data(), v.size(), 1);
     }
 
     // ---- beyond the reference surface: snapshot / restore (the reference has no checkpointing) ----

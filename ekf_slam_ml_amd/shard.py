@@ -36,6 +36,18 @@ def reduce_throughput(wall_s: float, corrections: float, filter_steps: float, de
     return float(tmax.item()), float(sums[0].item()), float(sums[1].item())
 
 
+def count_ranks(device="cpu"):
+    """Number of ranks that took part in the job, by an all-reduce of ones (1 without a process group): the bench line
+    reports it so that a multi-GPU figure can be told from one rank's."""
+    dist = _dist()
+    if dist is None:
+        return 1
+    import torch
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(round(float(one.item())))
+
+
 def gather_poses(poses, device="cpu"):
     """All ranks' [B_r, 3] pose blocks concatenated in global filter order (equal B_r required)."""
     dist = _dist()

@@ -135,6 +135,12 @@ ekf_status ekf_batch_get_touched(ekf_batch_handle hb, int* counts_out);
 ekf_status ekf_set_small_map_path(ekf_handle h, int enable);
 /* Blocks until every kernel queued on the handle's stream has finished. */
 ekf_status ekf_sync(ekf_handle h);
+/* Measurement hook (off by default): brackets every covariance-streaming launch (class 0: fused correction, rank-2
+ * stream, decision + correction) and every Mahalanobis scoring launch (class 1) of this filter with HIP events on
+ * its stream.  ekf_get_profile synchronises and returns the summed kernel milliseconds and launch counts per class
+ * since profiling was switched on. */
+ekf_status ekf_set_profiling(ekf_handle h, int enable);
+ekf_status ekf_get_profile(ekf_handle h, double ms[2], long long launches[2]);
 
 /* ---- batch of independent filters (BASELINE.json configs[4]) -------
  * Each filter is exactly one EKF_SLAM object; they share nothing.  Inputs are a compact
@@ -210,6 +216,10 @@ ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]);
  * rows per load/store group (2, 4 or 8).  <= 0 (nontemporal: < 0) restores the automatic choice.
  * Results do not depend on them, bit for bit. */
 ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal, int group_rows);
+/* Report hook: the instantiation ekf::k_rank2<group_rows, nontemporal, threads> and the rows per workgroup that a
+ * full-width eager correction of this pool launches (bench.py ties its PMC traffic record to this name). */
+ekf_status ekf_batch_rank2_variant(ekf_batch_handle hb, int* group_rows, int* nontemporal, int* threads,
+                                   int* rows_per_block);
 ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal, int group_rows);
 
 /* ---- on-device Monte-Carlo inputs and consistency statistics --------
@@ -300,6 +310,10 @@ ekf_status ekf_dense_set(ekf_dense_handle h, const float* F, const float* Sigma,
 /* Applies the propagation `iterations` times; elapsed_ms (nullable) = HIP-event time of the launches. */
 ekf_status ekf_dense_propagate(ekf_dense_handle h, int iterations, double* elapsed_ms);
 ekf_status ekf_dense_get_sigma(ekf_dense_handle h, float* out);
+/* Test / report hook: how one product of this handle is launched -- ld (N rounded up to 128), tiles = ld / 128 per
+ * side, n_big = 128 x 128 tiles run by the main kernel, n_tail = tiles cut into 64 x 64 quarters for the tail kernel
+ * on the second stream (0 when the tile count fits whole rounds of resident workgroups).  Any pointer may be NULL. */
+ekf_status ekf_dense_launch_info(ekf_dense_handle h, int* ld, int* tiles, int* n_big, int* n_tail);
 
 /* ---- laser-scan front end: rigid2d::CircleFitting, batched ----------
  * std::vector<Vector2D> approxCirclePositions(std::vector<double> ranges)

@@ -39,9 +39,10 @@ def _run_rank(rank, world, port, q):
         st, _, stats = ob.batch_run_known(log, ob.STRUCTURED, t_warm=1, nthreads=1, fast=False)
         wall, corr, fsteps = shard.reduce_throughput(1.0 + rank, stats["corrections"], count * (STEPS - 1))
         poses = shard.gather_poses(st[:, :3])
+        seen = shard.count_ranks()
         dist.barrier()
         if rank == 0:
-            q.put((wall, corr, fsteps, poses))
+            q.put((wall, corr, fsteps, poses, seen))
     finally:
         dist.destroy_process_group()
 
@@ -57,12 +58,13 @@ def test_two_ranks_equal_one_process():
     procs = [ctx.Process(target=_run_rank, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    wall, corr, fsteps, poses = q.get(timeout=120)
+    wall, corr, fsteps, poses, seen = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     full = synth.make_known_log(synth.config5(filters=TOTAL, steps=STEPS, n=N_LM))
     st, _, stats = ob.batch_run_known(full, ob.STRUCTURED, t_warm=1, nthreads=1, fast=False)
+    assert seen == 2                                     # all-reduce of ones: every rank took part
     assert wall == 2.0                                   # max over ranks
     assert corr == stats["corrections"] == TOTAL * (STEPS - 1) * 2
     assert fsteps == TOTAL * (STEPS - 1)
@@ -72,3 +74,4 @@ def test_two_ranks_equal_one_process():
 def test_reduction_without_process_group_is_identity():
     assert shard.reduce_throughput(1.5, 10, 5) == (1.5, 10, 5)
     assert shard.gather_poses(np.ones((2, 3))).shape == (2, 3)
+    assert shard.count_ranks() == 1

@@ -4,8 +4,37 @@ import numpy as np
 import pytest
 
 from ekf_slam_ml_amd import synth
+from parity import FP64_TOL, assert_parity
 
 pytestmark = pytest.mark.gpu
+
+
+def test_active_set_against_the_cpu_checker(hip, oracle):
+    """Direct comparison with the CPU restatement (not only with the eager HIP path): single filter n = 200 against
+    the dense-literal checker, and a pool at n = 400 against the structured one."""
+    T = 25
+    log = synth.make_known_log(synth.config2(steps=T))
+    f = hip.EKF_SLAM(200)
+    f.set_active_set(True)
+    o = oracle.OracleEKF(200, oracle.DENSE)
+    for t in range(T):
+        sensor, vis = log.expand_step(t)
+        f.prediction(log.twist[t, 0]); o.prediction(*log.twist[t, 0])
+        f.measurement(sensor, vis);    o.measurement(sensor, vis)
+    assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "active-set single filter vs dense checker")
+    f.close()
+
+    cfg = synth.config5(filters=6, steps=10, n=400)
+    blog = synth.make_known_log(cfg)
+    bt = hip.BatchEKF(6, 400)
+    bt.set_active_set(True)
+    bt.upload_known_log(blog.twist, blog.lm_idx, blog.z_xy, blog.init_xy)
+    bt.run_known()
+    st, cv, _ = oracle.batch_run_known(blog, oracle.STRUCTURED, want_cov=True, fast=False)
+    for b in range(6):
+        assert_parity(bt.state(b), bt.cov(b), st[b], cv[b], FP64_TOL, f"active-set pool filter {b} vs structured checker")
+    assert bt.touched().max() < 400   # the sparse path really was taken
+    bt.close()
 
 
 def test_single_filter_active_set_bitwise(hip):

@@ -78,3 +78,117 @@ def test_dense_reproduces_the_structured_prediction(hip, oracle):
     d.propagate(1)
     assert max(cov_err(d.sigma.astype(np.float64), o.cov).values()) < FP32_TOL
     d.close()
+
+
+# ---- the path the published N = 10003 figure comes from: > 768 tiles, tile count not divisible by 8 -> the main
+# ---- kernel runs whole rounds of 128 x 128 tiles (grouped order, several groups, ragged last group) and
+# ---- k_gemm_f32_tail finishes the rest as 64 x 64 quarters on the second stream (ekf_dense.hip launch_dense_gemm)
+
+def _tile_of(bid, tiles):
+    """host twin of ekf_dense.hip tile_of() for tile counts that do not divide 8 (no XCD remap)"""
+    assert (tiles * tiles) % 8 != 0
+    group_m = 8
+    per_group = group_m * tiles
+    g = bid // per_group
+    first_m = g * group_m
+    gm = min(group_m, tiles - first_m)
+    in_g = bid % per_group
+    return first_m + in_g % gm, in_g // gm
+
+
+def _tail_mask(info):
+    """boolean [tiles][tiles]: tiles computed by k_gemm_f32_tail"""
+    t = info["tiles"]
+    m = np.zeros((t, t), dtype=bool)
+    for bid in range(info["n_big"], info["n_big"] + info["n_tail"]):
+        tm, tn = _tile_of(bid, t)
+        m[tm, tn] = True
+    return m
+
+
+def test_dense_tail_path_exact_and_fp64(hip):
+    """ld = 3712 -> 29 x 29 = 841 tiles = 768 (one full round, 4 tile groups incl. a ragged one) + 73 tail tiles.
+    (1) exact-integer operands, all three matrices asymmetric, + Q: every element must be bit-exact, which pins the
+    tile -> (row, col) maps of BOTH kernels and the two-stream join; (2) random dense F against fp64 per block."""
+    N = 3600
+    d = hip.DensePropagator(N)
+    info = d.launch_info()
+    assert info["ld"] == 3712 and info["tiles"] == 29
+    assert info["n_big"] == 768 and info["n_tail"] == 73, info   # the test cannot silently take the one-kernel path
+    mask = _tail_mask(info)
+    assert mask.sum() == 73
+
+    rng = np.random.default_rng(29)
+    B = rng.integers(-1, 2, size=(N, N)).astype(np.float32)   # {-1, 0, 1}: every partial sum stays far below 2^24
+    Cm = rng.integers(-1, 2, size=(N, N)).astype(np.float32)
+    Q = rng.integers(-5, 6, size=(N, N)).astype(np.float32)
+    want = B.astype(np.float64) @ Cm.astype(np.float64) @ B.T.astype(np.float64) + Q
+    assert np.abs(want).max() < 2 ** 23
+    d.set(B, Cm, Q)
+    d.propagate(1)
+    got = d.sigma
+    bad = got.astype(np.float64) != want
+    if bad.any():
+        r, c = np.argwhere(bad)[0]
+        raise AssertionError(f"{bad.sum()} wrong elements, first at ({r},{c}) tile ({r // 128},{c // 128}) "
+                             f"tail={mask[r // 128, c // 128]}: got {got[r, c]} want {want[r, c]}")
+    # both products ran (T = B C is NN, T B^T is NT); a second application feeds the result back
+    d.set(np.eye(N, dtype=np.float32), got, np.zeros((N, N), dtype=np.float32))
+    d.propagate(1)
+    assert np.array_equal(d.sigma, got)
+
+    F = (np.eye(N) + rng.normal(size=(N, N)) / np.sqrt(N)).astype(np.float32)
+    A = rng.normal(size=(N, 96))
+    S = (A @ A.T / 96 + np.eye(N)).astype(np.float32)
+    Qd = np.diag(rng.uniform(1e-4, 1e-2, size=N)).astype(np.float32)
+    d.set(F, S, Qd)
+    d.propagate(1)
+    got = d.sigma.astype(np.float64)
+    want = _ref(F, S, Qd)
+    assert max(cov_err(got, want).values()) < FP32_TOL
+    # ... and tile by tile, so a wrong tail tile cannot hide in a per-block maximum taken over the whole matrix
+    scale = np.abs(want).max()
+    for tm, tn in np.argwhere(mask):
+        r0, c0 = tm * 128, tn * 128
+        blk_g, blk_w = got[r0:r0 + 128, c0:c0 + 128], want[r0:r0 + 128, c0:c0 + 128]
+        assert np.abs(blk_g - blk_w).max() / scale < FP32_TOL, (tm, tn)
+    d.close()
+
+
+def test_dense_full_size_n5000_rows_in_tail_tiles(hip):
+    """BASELINE.json configs[3] at its full size N = 10003 (n = 5000, ld = 10112, 79 x 79 = 6241 tiles = 8 rounds
+    of 768 + 97 tail tiles): rows sampled INSIDE tail tiles (and a few outside) against fp64."""
+    N = 10003
+    d = hip.DensePropagator(N)
+    info = d.launch_info()
+    assert info["ld"] == 10112 and info["tiles"] == 79 and info["n_big"] == 6144 and info["n_tail"] == 97, info
+    mask = _tail_mask(info)
+    rng = np.random.default_rng(4)
+    F = np.eye(N, dtype=np.float32) + rng.standard_normal((N, N), dtype=np.float32) * np.float32(0.05 / np.sqrt(N))
+    A = rng.standard_normal((N, 64), dtype=np.float32)
+    S = A @ A.T / np.float32(64) + np.eye(N, dtype=np.float32)
+    Q = np.zeros((N, N), dtype=np.float32)
+    Q[0, 0] = Q[1, 1] = Q[2, 2] = 1e-4
+    d.set(F, S, Q)
+    d.propagate(1)
+    got = d.sigma
+    tail_rows_blocks = np.unique(np.argwhere(mask)[:, 0])
+    rows = []
+    for tm in tail_rows_blocks:                       # one row in every block row that holds tail tiles
+        rows.append(min(N - 1, int(tm) * 128 + int(rng.integers(0, 128))))
+    rows += [0, 2, 5000, int(rng.integers(0, 9000))]  # and outside
+    rows = np.array(sorted(set(rows)))
+    F64 = F.astype(np.float64)
+    want = (F64[rows] @ S.astype(np.float64)) @ F64.T + Q[rows].astype(np.float64)
+    scale = np.abs(want).max()
+    err = np.abs(got[rows].astype(np.float64) - want) / scale
+    assert err.max() < FP32_TOL, f"rel err {err.max():.2e}"
+    # the sampled rows really cross tail tiles: check those column ranges on their own
+    hit = 0
+    for k, r in enumerate(rows):
+        for tn in np.nonzero(mask[r // 128])[0]:
+            c0 = int(tn) * 128
+            assert err[k, c0:min(N, c0 + 128)].max() < FP32_TOL
+            hit += 1
+    assert hit >= len(tail_rows_blocks)
+    d.close()

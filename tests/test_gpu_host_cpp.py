@@ -14,30 +14,51 @@ from parity import FP64_TOL, assert_parity
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 BIN = os.path.join(HERE, "cpp", "slam_replay")
+# the same replay over the DROP-IN class shim/rigid2d/{include,src} with the reference's own Twist2D / Vector2D /
+# DiffDrive (built in the authoring container by oracle/Makefile; it links reference objects, so it lives in oracle/_ref)
+SHIM_BIN = os.path.join(HERE, "..", "oracle", "_ref", "slam_replay_shim")
+VARIANTS = ["mirror", "shim"]
 
 
 def _hex(v):
     return float(v).hex()
 
 
-def _run(tmp_path, lines, n):
-    if not os.path.exists(BIN):
+def _run(tmp_path, lines, n, variant="mirror"):
+    """-> state, cov (None for the shim: the reference's class has no covariance accessor), known_list, tail"""
+    exe = BIN
+    if variant == "shim":
+        exe = SHIM_BIN
+        if not os.path.exists(exe):
+            pytest.skip("oracle/_ref/slam_replay_shim not built (needs /root/reference at build time)")
+    elif not os.path.exists(BIN):
         subprocess.run(["make", "-C", os.path.join(HERE, "cpp"), "-s"], check=True)
     log, out = tmp_path / "log.txt", tmp_path / "out.txt"
     log.write_text("\n".join(lines) + "\n")
-    subprocess.run([BIN, str(log), str(out)], check=True, timeout=300)
+    subprocess.run([exe, str(log), str(out)], check=True, timeout=300)
     vals = out.read_text().split()
     N = int(vals[0])
+    has_cov = N > 0
+    N = abs(N)
     assert N == 3 + 2 * n
     nums = [float.fromhex(v) if v.startswith(("0x", "-0x")) else float(v) for v in vals[1:]]
     state = np.array(nums[:N])
-    cov = np.array(nums[N:N + N * N]).reshape(N, N)
-    known = np.array(nums[N + N * N:N + N * N + n], dtype=np.uint8)
-    tail = nums[N + N * N + n:]
+    ncov = N * N if has_cov else 0
+    cov = np.array(nums[N:N + ncov]).reshape(N, N) if has_cov else None
+    known = np.array(nums[N + ncov:N + ncov + n], dtype=np.uint8)
+    tail = nums[N + ncov + n:]
     return state, cov, known, tail
 
 
-def test_known_association_node_loop(hip, oracle, tmp_path):
+def _check(state, cov, o, what):
+    if cov is None:  # shim: state only
+        assert_parity(state, o.cov, o.state, o.cov, FP64_TOL, what)
+    else:
+        assert_parity(state, cov, o.state, o.cov, FP64_TOL, what)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_known_association_node_loop(hip, oracle, tmp_path, variant):
     n, T = 20, 60
     log = synth.make_known_log(synth.config1(steps=T))
     lines = [f"0 {n} {T} {_hex(synth.WHEEL_BASE)} {_hex(synth.WHEEL_RADIUS)}"]
@@ -51,8 +72,8 @@ def test_known_association_node_loop(hip, oracle, tmp_path):
         assert tw[0] == log.twist[t, 0, 0] and tw[1] == log.twist[t, 0, 1]
         o.prediction(*tw)
         o.measurement(sensor, vis)
-    state, cov, known, tail = _run(tmp_path, lines, n)
-    assert_parity(state, cov, o.state, o.cov, FP64_TOL, "C++ node loop, known association")
+    state, cov, known, tail = _run(tmp_path, lines, n, variant)
+    _check(state, cov, o, f"C++ node loop ({variant}), known association")
     seen = np.zeros(n, dtype=np.uint8)
     for t in range(1, T):
         seen |= log.expand_step(t)[1]
@@ -60,7 +81,8 @@ def test_known_association_node_loop(hip, oracle, tmp_path):
     assert abs(tail[0] - o.state[0]) < 1e-9 and abs(tail[1] - o.state[1]) < 1e-9 and abs(tail[3] - o.state[-1]) < 1e-9
 
 
-def test_unknown_association_node_loop(hip, oracle, tmp_path):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_unknown_association_node_loop(hip, oracle, tmp_path, variant):
     n, T = 20, 50
     cfg = synth.config1(steps=T)
     cfg.seed = 5150
@@ -75,12 +97,13 @@ def test_unknown_association_node_loop(hip, oracle, tmp_path):
             lines.append(f"{j} {_hex(log.meas_xy[t, 0, j, 0])} {_hex(log.meas_xy[t, 0, j, 1])} 1")
         o.prediction(*log.twist[t, 0])
         o.data_association(log.meas_xy[t, 0, :J], known)
-    state, cov, known_cpp, _ = _run(tmp_path, lines, n)
+    state, cov, known_cpp, _ = _run(tmp_path, lines, n, variant)
     assert np.array_equal(known_cpp, known) and known.sum() >= 5
-    assert_parity(state, cov, o.state, o.cov, FP64_TOL, "C++ node loop, unknown association")
+    _check(state, cov, o, f"C++ node loop ({variant}), unknown association")
 
 
-def test_scan_pipeline_node_loop(hip, oracle, tmp_path):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_scan_pipeline_node_loop(hip, oracle, tmp_path, variant):
     """landmarks node + unknown_data_assoc node in C++: laser ranges -> ekfslam::CircleFitting ->
     EKF_SLAM::data_association, against the checker's circle fitting + filter."""
     n, T = 10, 40
@@ -99,6 +122,6 @@ def test_scan_pipeline_node_loop(hip, oracle, tmp_path):
         circles, _, _ = oracle.approx_circle_positions(scans[t])
         o.prediction(*log.twist[t, 0])
         o.data_association(circles, known)
-    state, cov, known_cpp, _ = _run(tmp_path, lines, n)
+    state, cov, known_cpp, _ = _run(tmp_path, lines, n, variant)
     assert np.array_equal(known_cpp, known) and known.sum() >= 3
-    assert_parity(state, cov, o.state, o.cov, FP64_TOL, "C++ scan -> circles -> association")
+    _check(state, cov, o, f"C++ scan -> circles -> association ({variant})")

@@ -8,15 +8,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--no-cpu-baseline $@"
+# kernel trace: the WHOLE bench line (every leg's kernels get a row); PMC passes: the contract leg only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || { tail -5 $OUT/trace.err; exit 1; }
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err || { tail -5 $OUT/pmc_fetch.err; exit 1; }
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err || { tail -5 $OUT/pmc_write.err; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --only-main $ARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err || { tail -5 $OUT/pmc_fetch.err; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --only-main $ARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err || { tail -5 $OUT/pmc_write.err; exit 1; }
 python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.txt
 cat $OUT/summary.txt
 # keep only the small files (the per-dispatch CSVs can be large)
 find $OUT -name '*.csv' -size +8M -delete
-# configs[3]: dense fp32 MFMA propagation under the same profiler
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dense_trace -- python3 $ROOT/tools/dense_bench.py 10003 5 > $OUT/dense_bench.txt 2> $OUT/dense_trace.err || { tail -5 $OUT/dense_trace.err; exit 1; }
-cat $OUT/dense_bench.txt
-cat $OUT/dense_trace/*/*kernel_stats.csv
