@@ -223,7 +223,7 @@ def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
     pose0 = np.zeros(3)
 
     def all_readings():
-        rel = synth._robot_frame(world, pose0)
+        rel = synth._robot_frame(world, pose0.reshape(1, 3))[0]
         return (rel + rng.normal(0.0, cfg.sensor_std, size=rel.shape)).reshape(-1)
 
     def build(profile):
@@ -271,7 +271,7 @@ def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
         o.state, o.cov = snap_state, snap_cov
         o.set_init_flag(1)
         ko = np.ones(n, dtype=np.uint8)
-        csteps = min(full_steps, 60)
+        csteps = full_steps
         t0 = time.perf_counter()
         cm = 0
         for t in range(csteps):
@@ -597,6 +597,57 @@ def main():
                         "(LDS-resident step kernel); landmarks are appended in discovery order, so each filter's "
                         "corrections stream only its leading 3 + 2*known block (bit-identical to the full-width update, "
                         "tests/test_gpu_batch_unknown.py).  The large-prefix regime is `unknown_association_large_prefix`"}
+    # The LARGE-prefix regime of the same path: every robot explores a map it has already surveyed (phase A, untimed:
+    # a host-written known-association log corrects each of the n landmarks once from the origin), then runs unknown
+    # association against all n of them -- every reading is scored against 1000 landmarks (one per wavefront,
+    # ekf_slam.cpp:300-309) and the winner corrected at full width (:331-390): four launches per measurement slot.
+    if not a.no_unknown and not a.host_log:
+        Bl, J, Tu = min(B, 128), 8, 1 + W + K
+        lb = capi.BatchEKF(Bl, n, device=local)
+        lworld = synth.make_world(n, 12.0, 0.6, 3)
+        rng = np.random.default_rng(1000 + rank)
+        vm = 64
+        Ta = 1 + (n + vm - 1) // vm
+        a_lm = np.full((Ta, Bl, vm), -1, dtype=np.int32)
+        a_z = np.zeros((Ta, Bl, vm, 2))
+        for t in range(1, Ta):
+            idx = np.arange((t - 1) * vm, min(n, t * vm))
+            a_lm[t, :, :len(idx)] = idx
+            a_z[t, :, :len(idx)] = lworld[idx][None] + rng.normal(0.0, 0.005, size=(Bl, len(idx), 2))
+        a_init = (lworld[None] + rng.normal(0.0, 0.005, size=(Bl, n, 2))).reshape(Bl, 2 * n)
+        lb.upload_known_log(np.zeros((Ta, Bl, 2)), a_lm, a_z, a_init)  # robot at rest at the origin: robot frame = world frame
+        lb.run_known(0, Ta)
+        lb.set_known_counts(n)
+        lcfg = synth.config3(steps=Tu)
+        lcfg.filters, lcfg.first_filter_id, lcfg.n = Bl, rank * Bl, n
+        lb.simulate_unknown_log(lcfg, lworld, jmax=J)
+        lb.run_unknown(0, 1 + W)
+        fence()
+        t0 = time.perf_counter()
+        sl = lb.run_unknown(1 + W, Tu, time_kernels=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fence()
+        lwall, lcorr, lsteps = shard.reduce_throughput(t1 - t0, float(sl["corrections"]), float(sl["filter_steps"]),
+                                                       device=red_dev)
+        if rank == 0:
+            kc = lb.known_counts()
+            dec = lb.decisions()[1 + W:Tu]
+            nmeas = int((dec > -2).sum()) * world
+            r2_s = sl["rank2_ms"] / max(sl["rank2_launches"], 1) * 1e-3
+            out["unknown_association_large_prefix"] = {
+                "value": lsteps / lwall, "unit": "filter steps/s (1 step = prediction + data_association of <= 8 readings)",
+                "measurements_per_s": nmeas / lwall, "scores_per_s": nmeas * float(n) / lwall,
+                "corrections_per_s": lcorr / lwall, "filters_per_gpu": Bl,
+                "known_landmarks_min": int(kc.min()), "known_landmarks_max": int(kc.max()),
+                "measurement_slots": sl["rank2_launches"], "rank2_avg_ms": r2_s * 1e3,
+                "rank2_share_of_time": sl["rank2_ms"] / sl["elapsed_ms"],
+                "rank2_GBps_if_every_filter_corrects": Bl * 16.0 * N * N / r2_s / 1e9,
+                "mc_consistency": lb.mc_stats(Tu - 1),
+                "note": "known_count = n for every filter (map surveyed through the known-association path first): the "
+                        "discovered prefix is the whole state, so every slot is k_maha over n landmarks + k_assoc_decide + "
+                        "k_gain + a full-width k_rank2"}
+        lb.close()
     # The reference's own operating point at Monte-Carlo scale: configs[0] (n = 20, 1000 steps) for 8192 robots per
     # GPU, inputs simulated on the device, the whole run ONE launch with every covariance resident in LDS.
     if not a.no_small and not a.host_log:

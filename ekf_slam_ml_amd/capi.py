@@ -41,7 +41,7 @@ SYMBOLS = [
     "ekf_default_lidar_params", "ekf_batch_simulate_unknown_log", "ekf_batch_download_unknown_log", "ekf_simulate_scans",
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
     "ekf_dense_launch_info", "ekf_batch_rank2_variant",
-    "ekf_set_profiling", "ekf_get_profile",
+    "ekf_set_profiling", "ekf_get_profile", "ekf_batch_set_known_counts",
 ]
 
 
@@ -178,6 +178,7 @@ def load():
         "ekf_dense_get_sigma": [h, _fp],
         "ekf_dense_launch_info": [h, _ip, _ip, _ip, _ip],
         "ekf_batch_rank2_variant": [h, _ip, _ip, _ip, _ip],
+        "ekf_batch_set_known_counts": [h, _ip],
         "ekf_set_profiling": [h, C.c_int],
         "ekf_get_profile": [h, _dp, C.POINTER(C.c_longlong)],
     }
@@ -486,6 +487,11 @@ class BatchEKF:
 
     def set_small_map_path(self, enable=True):
         _check(self._lib.ekf_batch_set_small_map_path(self._h, int(bool(enable))))
+
+    def set_known_counts(self, counts):
+        """every filter's known_count (leading run of its known_list) -- the batch twin of the known_list argument"""
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(counts, dtype=np.int32), (self.B,)))
+        _check(self._lib.ekf_batch_set_known_counts(self._h, c.ctypes.data_as(_ip)))
 
     def known_counts(self):
         out = np.empty(self.B, dtype=np.int32)

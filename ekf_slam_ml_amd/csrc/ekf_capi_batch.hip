@@ -410,6 +410,31 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     return EKF_OK;
 }
 
+ekf_status ekf_batch_set_known_counts(ekf_batch_handle hb, const int* counts) {
+    if (!hb || !counts) return fail(EKF_ERR_INVALID, "null argument");
+    Pool& P = hb->pool;
+    EKFC(P.use());
+    for (int b = 0; b < P.pv.B; b++)
+        if (counts[b] < 0 || counts[b] > P.pv.n) return fail(EKF_ERR_INVALID, "known count must lie in 0..n");
+    int* dev = nullptr;
+    HIPC(hipMalloc((void**)&dev, sizeof(int) * P.pv.B));
+    ekf_status st = P.upload(dev, counts, sizeof(int) * P.pv.B);
+    if (st == EKF_OK) {
+        ekf::launch_assoc_begin(P.pv, dev, 0, P.stream);
+        st = checked_launch();
+    }
+    hipError_t e = hipStreamSynchronize(P.stream);
+    (void)hipFree(dev);
+    if (st == EKF_OK && e != hipSuccess) st = fail(EKF_ERR_HIP, hipGetErrorString(e));
+    if (st != EKF_OK) return st;
+    // landmarks below a caller-declared count may carry any covariance: no discovered-prefix structure below it
+    int m = 0;
+    for (int b = 0; b < P.pv.B; b++) if (counts[b] > m) m = counts[b];
+    if (m > P.touched_hwm) P.touched_hwm = m;
+    P.dev_known_count = -1;
+    return EKF_OK;
+}
+
 ekf_status ekf_batch_get_known_counts(ekf_batch_handle hb, int* out) {
     if (!hb || !out) return fail(EKF_ERR_INVALID, "null argument");
     Pool& P = hb->pool;

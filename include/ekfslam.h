@@ -198,6 +198,11 @@ ekf_status ekf_batch_upload_unknown_log(ekf_batch_handle hb, const ekf_unknown_l
  * corrections actually applied (decided on the device). */
 ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, int time_kernels,
                                  ekf_run_stats* stats);
+/* The batch twin of the caller-owned known_list argument of data_association(): sets every filter's known_count
+ * (the leading run of its known_list, ekf_slam.cpp:281-288) to counts[b] in 0..n -- e.g. to continue with unknown
+ * association on a map built through the known-association path, whose first call initialises all n landmarks
+ * (:113-128).  Landmarks below the count are treated as possibly corrected (no discovered-prefix shortcut). */
+ekf_status ekf_batch_set_known_counts(ekf_batch_handle hb, const int* counts);
 /* known_count of every filter: out[B]. */
 ekf_status ekf_batch_get_known_counts(ekf_batch_handle hb, int* out);
 /* Decisions of the uploaded unknown log's steps run so far: out = [T][B][jmax], landmark index

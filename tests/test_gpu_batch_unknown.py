@@ -218,3 +218,56 @@ def test_batch_unknown_then_known_then_unknown(hip, oracle, n):
         assert bt.known_counts()[b] == int(known.sum())
         assert_parity(bt.state(b), bt.cov(b), o.state, o.cov, FP64_TOL, f"mixed loops, filter {b}")
     bt.close()
+
+
+def test_surveyed_map_then_unknown_association(hip, oracle):
+    """ekf_batch_set_known_counts: a map built through the known-association path (whose first call initialises all n
+    landmarks, ekf_slam.cpp:113-128) is then used with unknown association, known_list all true from the start -- the
+    batch twin of passing a prefilled known_list to data_association().  Every reading is scored against ALL n
+    landmarks and corrected at full width; decisions, state and covariance against the dense checker."""
+    n, B, T = 40, 3, 25
+    ucfg = synth.SimConfig(n=n, steps=T, filters=B, seed=99, half_extent=2.0, min_spacing=0.35, max_visible_dis=0.9, vmax=5)
+    ulog = synth.make_unknown_log(ucfg)
+    world = ulog.world
+    rng = np.random.default_rng(5)
+    vm = 16
+    Ta = 1 + (n + vm - 1) // vm
+    lm = np.full((Ta, B, vm), -1, dtype=np.int32)
+    z = np.zeros((Ta, B, vm, 2))
+    for t in range(1, Ta):
+        idx = np.arange((t - 1) * vm, min(n, t * vm))
+        lm[t, :, :len(idx)] = idx
+        z[t, :, :len(idx)] = world[idx][None] + rng.normal(0.0, 0.005, size=(B, len(idx), 2))
+    init = (world[None] + rng.normal(0.0, 0.005, size=(B, n, 2))).reshape(B, 2 * n)
+    tw0 = np.zeros((Ta, B, 2))
+    snap = []
+    for small in (True, False):   # LDS-resident step kernel (N = 83) / four launches per measurement slot
+        bt = hip.BatchEKF(B, n)
+        bt.set_small_map_path(small)
+        bt.upload_known_log(tw0, lm, z, init)
+        bt.run_known()
+        bt.set_known_counts(n)
+        assert np.array_equal(bt.known_counts(), np.full(B, n))
+        bt.upload_unknown_log(ulog.twist, ulog.count, ulog.meas_xy)
+        st = bt.run_unknown(0, T)
+        dec = bt.decisions()
+        matched = 0
+        for b in range(B):
+            o = oracle.OracleEKF(n, oracle.DENSE)
+            for t in range(Ta):
+                o.prediction(0.0, 0.0)
+                o.measurement_compact(init[b], lm[t, b], z[t, b])
+            known = np.ones(n, dtype=np.uint8)
+            o, known, d = _oracle_replay(oracle, ulog, b, n, 0, T, o, known)
+            assert np.array_equal(dec[:, b], d), f"filter {b}: decisions differ"
+            assert_parity(bt.state(b), bt.cov(b), o.state, o.cov, FP64_TOL, f"surveyed map, filter {b}")
+            good = d >= 0
+            matched += int(good.sum())
+            assert np.array_equal(d[good], ulog.truth_idx[:, b][good])   # and the association is the true one
+        assert st["corrections"] == matched and matched > 50
+        snap.append([(bt.state(b), bt.cov(b)) for b in range(B)])
+        with pytest.raises(hip.EkfError):
+            bt.set_known_counts(n + 1)
+        bt.close()
+    for (s0, c0), (s1, c1) in zip(*snap):
+        assert np.array_equal(s0, s1) and np.array_equal(c0, c1)
