@@ -42,6 +42,7 @@ SYMBOLS = [
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
     "ekf_dense_launch_info", "ekf_batch_rank2_variant",
     "ekf_set_profiling", "ekf_get_profile", "ekf_batch_set_known_counts",
+    "ekf_set_cooperative_tick", "ekf_cooperative_trace",
 ]
 
 
@@ -180,6 +181,8 @@ def load():
         "ekf_batch_rank2_variant": [h, _ip, _ip, _ip, _ip],
         "ekf_batch_set_known_counts": [h, _ip],
         "ekf_set_profiling": [h, C.c_int],
+        "ekf_set_cooperative_tick": [h, C.c_int, C.c_int],
+        "ekf_cooperative_trace": [h, C.c_int, C.POINTER(C.c_longlong), _ip],
         "ekf_get_profile": [h, _dp, C.POINTER(C.c_longlong)],
     }
     for name, argtypes in sig.items():
@@ -339,6 +342,18 @@ class EKF_SLAM:
 
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
+
+    def set_cooperative_tick(self, enable=True, workgroups=0):
+        """mid-size maps: prediction() + measurement() of a tick as ONE launch, Sigma resident in LDS (default on)"""
+        _check(self._lib.ekf_set_cooperative_tick(self._h, int(bool(enable)), int(workgroups)))
+
+    def cooperative_trace(self, enable=True, fetch=False):
+        """phase stamps (100 MHz ticks) of the last cooperative tick: array [workgroups, 64], or None"""
+        out = np.zeros((256, 64), dtype=np.int64)
+        g = C.c_int(0)
+        _check(self._lib.ekf_cooperative_trace(self._h, int(bool(enable)), out.ctypes.data_as(C.POINTER(C.c_longlong)) if fetch else None,
+                                               C.byref(g)))
+        return out[:g.value] if fetch else None
 
     def set_profiling(self, enable=True):
         """HIP-event timing of every covariance-streaming (class 0) and scoring (class 1) launch; resets the sums"""

@@ -77,6 +77,11 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
     HIPC(hipMemcpyAsync(c.pv.touch_count, a.pv.touch_count, sizeof(int), hipMemcpyDeviceToDevice, c.stream));
     c.active_prefix = a.active_prefix;
     c.fused = a.fused;
+    c.coop = a.coop;
+    if (a.coop_target != c.coop_target) {
+        c.coop_target = a.coop_target;
+        c.coop_R = ekf::coop_rows_per_wg(c.pv.N, c.cus, c.coop_target);
+    }
     return c.sync();
 }
 
@@ -114,6 +119,46 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
             if (visible[i]) { if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1; break; }
         for (int i = 0; i < n; i++)
             if (visible[i]) P.note_touched(i);
+        return checked_launch();
+    }
+    if (P.coop_ok()) {
+        // mid-size map (e.g. n = 200): the whole call -- and the prediction() before it -- in ONE launch with Sigma
+        // resident in the LDS of a few dozen workgroups, one workgroup-to-all hand-off per visible landmark (ekf_coop.hip)
+        EKFC(P.ensure_coop());
+        std::vector<int> vl(1, 0);
+        for (int i = 0; i < n; i++)
+            if (visible[i]) {
+                vl.push_back(i);
+                if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1;
+                P.note_touched(i);
+            }
+        vl[0] = (int)vl.size() - 1;
+        EKFC(P.upload2(P.coop_in, sensor_xy, sizeof(double) * 2 * n, vl.data(), sizeof(int) * vl.size()));
+        ekf::CoopArgs ca{};
+        ca.sensor = P.coop_in;
+        ca.vlist = reinterpret_cast<const int*>(P.coop_in + 2 * (size_t)n);
+        ca.xchg = P.coop_xchg;
+        ca.flags = P.coop_flags;
+        ca.err = P.coop_err;
+        if (++P.coop_epoch == 0) P.coop_epoch = 1;
+        ca.epoch = P.coop_epoch;
+        ca.xstride = P.coop_xstride;
+        ca.rows_per_wg = P.coop_R;
+        ca.do_init = !P.init_flag;
+        ca.has_twist = P.pred_pending ? 1 : 0;
+        ca.dtheta = P.pred_dth;
+        ca.dx = P.pred_dx;
+        ca.sigma_next = P.sigma_alt;
+        ca.state_next = P.state_fz;
+        ca.trace = P.coop_trace;
+        EKFC(P.prof_begin(0));
+        ekf::launch_coop_measure(P.pv, ca, P.stream);
+        EKFC(P.prof_end());
+        std::swap(P.pv.sigma, P.sigma_alt);
+        std::swap(P.pv.state, P.state_fz);
+        P.alt_synced = false;
+        P.pred_pending = false;
+        P.init_flag = 1;
         return checked_launch();
     }
     EKFC(P.upload2(P.sensor_dev, sensor_xy, sizeof(double) * 2 * n, visible, (size_t)n));
@@ -344,6 +389,36 @@ ekf_status ekf_set_fused_correction(ekf_handle h, int enable) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     h->pool.fused = enable ? 1 : 0;
     h->pool.alt_synced = false;
+    return EKF_OK;
+}
+
+ekf_status ekf_set_cooperative_tick(ekf_handle h, int enable, int workgroups) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    Pool& P = h->pool;
+    EKFC(P.use());  // (a prediction deferred under the old setting happens now)
+    P.coop = enable ? 1 : 0;
+    P.coop_target = workgroups > 0 ? workgroups : 0;
+    P.coop_R = P.pv.B == 1 ? ekf::coop_rows_per_wg(P.pv.N, P.cus, P.coop_target) : 0;
+    return EKF_OK;
+}
+
+ekf_status ekf_cooperative_trace(ekf_handle h, int enable, long long* out, int* workgroups) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    Pool& P = h->pool;
+    EKFC(P.use());
+    const size_t cnt = (size_t)256 * ekf::kCoopTraceSlots;
+    if (out && P.coop_trace) {
+        EKFC(P.download(out, P.coop_trace, sizeof(long long) * cnt));
+        if (workgroups) *workgroups = P.coop_R > 0 ? (P.pv.N - 3 + P.coop_R - 1) / P.coop_R : 0;
+    }
+    if (enable && !P.coop_trace) {
+        EKFC(P.dalloc(&P.coop_trace, cnt));
+        HIPC(hipMemsetAsync(P.coop_trace, 0, sizeof(long long) * cnt, P.stream));
+    } else if (!enable && P.coop_trace) {
+        HIPC(hipStreamSynchronize(P.stream));
+        HIPC(hipFree(P.coop_trace));
+        P.coop_trace = nullptr;
+    }
     return EKF_OK;
 }
 

@@ -200,6 +200,42 @@ struct Pool {
         return EKF_OK;
     }
 
+    // One-launch prediction() + measurement() tick of a mid-size single filter with Sigma resident in LDS (ekf_coop.hip)
+    int coop = 1;            // ekf_set_cooperative_tick
+    int coop_R = 0;          // rows per workgroup; 0 = the map does not fit (or not a single filter)
+    int coop_target = 0;     // requested number of workgroups (0 = default)
+    int cus = 0;
+    double* coop_in = nullptr;     // [2n] sensor_reading | [1 + n] ints: V, visible landmarks
+    double* coop_xchg = nullptr;   // [n][coop_xstride]
+    unsigned* coop_flags = nullptr;
+    unsigned* coop_err = nullptr;  // host-mapped word
+    unsigned coop_epoch = 0;
+    int coop_xstride = 0;
+    long long* coop_trace = nullptr;   // [256][kCoopTraceSlots], only while ekf_cooperative_trace is on
+    bool coop_ok() const {
+        return coop && coop_R > 0 && pv.B == 1 && pend_cap == 0 && !active_set && pv.n > 0 && pv.N > ekf::small_max_dim();
+    }
+    ekf_status ensure_coop() {
+        if (!sigma_alt) {  // the second covariance / state buffer the tick writes into (shared with the fused correction)
+            EKFC(dalloc(&sigma_alt, (size_t)pv.B * pv.sigma_stride));
+            EKFC(dalloc(&state_fz, (size_t)pv.B * pv.ld));
+            EKFC(dalloc(&assoc_alt, (size_t)pv.B));
+            EKFC(dalloc(&terms, (size_t)pv.B * (pv.n > 0 ? pv.n : 1) * 16));
+            alt_synced = false;
+        }
+        if (!coop_xchg) {
+            coop_xstride = 2 * pv.ld + 16;
+            EKFC(dalloc(&coop_in, (size_t)2 * pv.n + (size_t)(pv.n + 2 + 1) / 2));
+            EKFC(dalloc(&coop_xchg, (size_t)pv.n * coop_xstride));
+            EKFC(dalloc(&coop_flags, (size_t)pv.n));
+            HIPC(hipMemsetAsync(coop_flags, 0, sizeof(unsigned) * pv.n, stream));
+            HIPC(hipHostMalloc((void**)&coop_err, 64, hipHostMallocMapped));
+            *coop_err = 0;
+            HIPC(ekf::coop_prepare());
+        }
+        return EKF_OK;
+    }
+
     bool fused_ok() const { return fused && pv.B == 1 && pend_cap == 0 && !active_set; }
     ekf_status ensure_alt() {
         if (!sigma_alt) {
@@ -316,7 +352,7 @@ struct Pool {
     bool pred_pending = false;
     double pred_dth = 0.0, pred_dx = 0.0;
     bool defer_predict_ok() const {
-        return pv.B == 1 && small_path && pend_cap == 0 && pv.n > 0 && pv.N <= ekf::small_max_dim();
+        return (pv.B == 1 && small_path && pend_cap == 0 && pv.n > 0 && pv.N <= ekf::small_max_dim()) || coop_ok();
     }
     void launch_predict_now(double dth, double dx) {
         // Rows/columns of landmarks this object never corrected are exactly zero against the pose block
@@ -327,6 +363,9 @@ struct Pool {
     }
     ekf_status use(bool settle = true) {
         HIPC(hipSetDevice(device));
+        if (coop_err && *coop_err)
+            return fail(EKF_ERR_HIP, "cooperative measurement tick gave up waiting for a hand-off (slot " +
+                                         std::to_string(*coop_err - 1) + "): the filter state is invalid");
         if (settle && pred_pending) {
             pred_pending = false;
             launch_predict_now(pred_dth, pred_dx);
@@ -365,6 +404,8 @@ struct Pool {
         pv.ld = round_up(pv.N, 16);
         pv.B = B;
         pv.sigma_stride = (size_t)pv.N * pv.ld;
+        cus = prop.multiProcessorCount;
+        coop_R = B == 1 ? ekf::coop_rows_per_wg(pv.N, cus, coop_target) : 0;
         EKFC(dalloc(&pv.sigma, (size_t)B * pv.sigma_stride));
         EKFC(dalloc(&pv.state, (size_t)B * pv.ld));
         EKFC(dalloc(&pv.Kg, (size_t)B * 2 * pv.ld));
@@ -404,9 +445,12 @@ struct Pool {
         void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, pv.touch_flag, pv.touch_list,
                         pv.touch_count, scores, meas_dev,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
-                        Uf, Vf, state_alt, sigma_alt, state_fz, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter};
+                        Uf, Vf, state_alt, sigma_alt, state_fz, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
+                        coop_in, coop_xchg, coop_flags, coop_trace};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
+        if (coop_err) (void)hipHostFree(coop_err);
+        coop_err = nullptr;
         stage_in.release();
         stage_out.release();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);

@@ -133,6 +133,20 @@ ekf_status ekf_batch_get_touched(ekf_batch_handle hb, int* counts_out);
  * LDS-resident launch instead of 2 launches per visible landmark; enable != 0 is the default.  Bit-identical
  * to the multi-kernel path. */
 ekf_status ekf_set_small_map_path(ekf_handle h, int enable);
+/* Single filter, mid-size maps (104 < N = 3 + 2n, as long as N rows of Sigma spread over the device's CUs fit their
+ * LDS: n up to about 700): ekf_predict + ekf_measure_known of one node tick run as ONE launch -- the rows of Sigma are
+ * split over `workgroups` workgroups (0 = automatic, about 50; at most one per CU) that keep them in LDS for all the
+ * visible landmarks of the call and exchange one 2 x N block per landmark inside the launch (enable != 0, default).
+ * ekf_predict then launches nothing by itself: the twist rides along with the next ekf_measure_known (any other call
+ * in between makes the pending prediction happen first).  enable == 0: one launch per landmark (ekf_set_fused_correction).
+ * Bit-identical either way. */
+ekf_status ekf_set_cooperative_tick(ekf_handle h, int enable, int workgroups);
+/* Diagnostics of the cooperative tick: while enabled, lane 0 of every workgroup stamps the device's 100 MHz wall clock at
+ * its phase boundaries.  out (nullable) receives the stamps of the LAST tick, [256][64] (row = workgroup; slots: 0 start,
+ * 1 image loaded, 2 prediction done, 3 readings converted, then for correction v < 9 at 4 + 6v: begin, terms ready
+ * (owner) / flag seen (others), block published / loaded, K ready, rows updated; 62 loop done, 63 written back);
+ * workgroups (nullable) = workgroups in use. */
+ekf_status ekf_cooperative_trace(ekf_handle h, int enable, long long* out, int* workgroups);
 /* Blocks until every kernel queued on the handle's stream has finished. */
 ekf_status ekf_sync(ekf_handle h);
 /* Measurement hook (off by default): brackets every covariance-streaming launch (class 0: fused correction, rank-2
