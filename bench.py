@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--delayed-k", type=int, default=32,
                     help="also time the delayed rank-2k update with this many corrections per flush (0 = skip)")
     ap.add_argument("--no-active-set", action="store_true", help="skip the active-set leg")
+    ap.add_argument("--no-call-fused", action="store_true", help="skip the call-fused (one pass per measurement() call) leg")
     ap.add_argument("--no-unknown", action="store_true", help="skip the batched unknown-association legs")
     ap.add_argument("--no-small", action="store_true", help="skip the small-map (n = 20) Monte-Carlo leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs[1..3] legs (single filters, dense)")
@@ -58,7 +59,7 @@ def parse():
     ap.add_argument("--nt", type=int, default=-1)
     a = ap.parse_args()
     if a.only_main:
-        a.no_active_set = a.no_unknown = a.no_small = a.no_configs = True
+        a.no_active_set = a.no_unknown = a.no_small = a.no_configs = a.no_call_fused = True
         a.delayed_k = 0
     return a
 
@@ -482,6 +483,44 @@ def main():
                 delayed["max_abs_state_diff_vs_eager"] = float(np.abs(dstate - eager_state[:len(dstate)]).max())
         bt.set_update_mode(0)
 
+    # Separately reported leg: the SAME steps with every measurement() call fused (ekf_callfused.hip) -- the gains and
+    # H*Sigma rows of both corrections of a call come from thin panels of Sigma, then ONE pass over Sigma applies them in
+    # order: bit-identical to the eager leg, 16 N^2 bytes per CALL instead of per correction.  Declared bytes per
+    # correction: 16 N^2 / V + the panel reads and factor traffic of the factor kernel.
+    callf = None
+    if not a.no_call_fused:
+        bt.reset()
+        bt.set_call_fused(True)
+        bt.run_known(0, 1 + W)
+        fence()
+        t0 = time.perf_counter()
+        sc = bt.run_known(1 + W, 1 + W + K, time_kernels=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fence()
+        cwall, ccorr, _ = shard.reduce_throughput(t1 - t0, float(sc["corrections"]), float(sc["filter_steps"]),
+                                                  device=red_dev)
+        if rank == 0:
+            cstate = np.stack([bt.state(b) for b in range(min(B, 4))])
+            Vc = 2.0
+            Nf = float(N)
+            per_corr = 16.0 * Nf * Nf / Vc + (2.0 * (3.0 + 2.0 * Vc) * 8.0 * Nf + 4.0 * 8.0 * Nf * 2.0) / Vc
+            pass_s = sc["rank2_ms"] / max(sc["rank2_launches"], 1) * 1e-3
+            callf = {"value": ccorr / cwall, "unit": "update steps/s", "ms_per_step": cwall / K * 1e3,
+                     "passes": sc["rank2_launches"], "pass_avg_ms": pass_s * 1e3,
+                     "pass_GBps": sc["rank2_bytes_per_launch"] / pass_s / 1e9,
+                     "pass_frac_of_8TBps": sc["rank2_bytes_per_launch"] / pass_s / 1e9 / HBM_PEAK_GBS,
+                     "pass_share_of_time": sc["rank2_ms"] / sc["elapsed_ms"],
+                     "declared_bytes_per_correction": per_corr,
+                     "achieved_GBps_on_declared_bytes": ccorr / world * per_corr / cwall / 1e9,
+                     "frac_of_8TBps": ccorr / world * per_corr / cwall / 1e9 / HBM_PEAK_GBS,
+                     "speedup_vs_eager": (ccorr / cwall) / (corr / wall),
+                     "bit_identical_to_eager": bool(np.array_equal(cstate, eager_state[:len(cstate)])),
+                     "note": "exact: every element of Sigma takes the V = 2 rank-2 corrections of a call in order in one "
+                             "read-modify-write (tests/test_gpu_callfused.py); the eager per-correction stream above stays "
+                             "the contract path of `value` / `roofline`"}
+        bt.set_call_fused(False)
+
     # Third, separately reported leg: the eager correction restricted to the rows of the TOUCHED set (exact,
     # bit-identical; SURVEY.md section 7 "exact active-set sparsity").  Its cost depends on how many landmarks
     # a filter has corrected so far (here <= 2 per step), not on n -- it says nothing about the dense roofline.
@@ -544,6 +583,8 @@ def main():
             out["roofline"]["traffic_note"] = why_not
         if delayed is not None:
             out["delayed_update"] = delayed
+        if callf is not None:
+            out["call_fused_update"] = callf
         if active is not None:
             out["active_set_update"] = active
         if not a.host_log:

@@ -42,7 +42,7 @@ SYMBOLS = [
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
     "ekf_dense_launch_info", "ekf_batch_rank2_variant",
     "ekf_set_profiling", "ekf_get_profile", "ekf_batch_set_known_counts",
-    "ekf_set_cooperative_tick", "ekf_cooperative_trace",
+    "ekf_set_cooperative_tick", "ekf_cooperative_trace", "ekf_set_call_fused", "ekf_batch_set_call_fused",
 ]
 
 
@@ -182,6 +182,8 @@ def load():
         "ekf_batch_set_known_counts": [h, _ip],
         "ekf_set_profiling": [h, C.c_int],
         "ekf_set_cooperative_tick": [h, C.c_int, C.c_int],
+        "ekf_set_call_fused": [h, C.c_int],
+        "ekf_batch_set_call_fused": [h, C.c_int],
         "ekf_cooperative_trace": [h, C.c_int, C.POINTER(C.c_longlong), _ip],
         "ekf_get_profile": [h, _dp, C.POINTER(C.c_longlong)],
     }
@@ -342,6 +344,10 @@ class EKF_SLAM:
 
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
+
+    def set_call_fused(self, enable=True):
+        """measurement() as two launches per call (factor panels + one pass over Sigma); default on, bit-identical"""
+        _check(self._lib.ekf_set_call_fused(self._h, int(bool(enable))))
 
     def set_cooperative_tick(self, enable=True, workgroups=0):
         """mid-size maps: prediction() + measurement() of a tick as ONE launch, Sigma resident in LDS (default on)"""
@@ -540,6 +546,10 @@ class BatchEKF:
 
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_batch_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
+
+    def set_call_fused(self, enable=True):
+        """every measurement() call of the pool as factor panels + ONE pass over Sigma (exact; default off for pools)"""
+        _check(self._lib.ekf_batch_set_call_fused(self._h, int(bool(enable))))
 
     def rank2_kernel(self):
         """name of the k_rank2 instantiation a full-width eager correction of this pool launches, + rows per workgroup"""

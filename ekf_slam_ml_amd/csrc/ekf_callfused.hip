@@ -1,0 +1,329 @@
+// ekf_callfused.hip -- a whole measurement() call (ekf_slam.cpp:108-197) as TWO launches, whatever the number V of
+// visible landmarks: Sigma is streamed ONCE per call instead of once per landmark, and the result is still
+// bit-identical to the per-landmark path (same operations on every element, in the same order).
+//
+// Observation.  Correction v of a call updates Sigma <- Sigma - K_v G_v with K_v = Sigma H_v^T S_v^-1 (N x 2) and
+// G_v = H_v Sigma (2 x N), all taken from the covariance AFTER corrections 0..v-1.  H_v has the five non-zero columns
+// c5(v) = {0, 1, 2, 3+2i_v, 4+2i_v}.  Let C = {0,1,2} + {3+2i_v, 4+2i_v : v < V} be the "core" index set of the call
+// (Nc = 3 + 2V indices).  Then
+//   * H_v, S_v, nu_v depend only on the core block Sigma[C, C] and the core state -- a (3+2V)-dimensional filter that
+//     is closed under the corrections of the call (its update needs K_v[C] and G_v[C], which come from the block itself);
+//   * G_v[c] for ANY column c needs only column c of the row panel Sigma[C, :], and that column's update
+//     Sigma[C, c] -= K_v[C] G_v[c] needs nothing else: the panel recursion is independent per column;
+//   * K_v[r] for ANY row r needs only row r of the column panel Sigma[:, C], whose update
+//     Sigma[r, C] -= K_v[r] G_v[C] is independent per row.
+// So all V factor pairs (K_v, G_v) of a call follow from O(V^2 N) work on two thin panels, without touching the bulk
+// of Sigma, and every other element then takes its V rank-2 updates in ONE read-modify-write:
+//       x <- ((x - (K_0[r].G_0[c])) - (K_1[r].G_1[c])) - ...      -- the very sequence the per-landmark path applies.
+//
+// k_call_factors  grid (column/row slices of 256, filters).  Wave 0 of every workgroup runs the core filter (the
+//                 transcendental chain, lane-parallel: wave_terms) one correction AHEAD of the other waves, which carry
+//                 one panel column and one panel row per thread in registers and emit the factors U = K, Vf = G.
+//                 The state update state += K_v nu_v (:186-187) is row-local and goes out of place (state_out).
+// k_rank2v        the streaming pass: Sigma[r][c] -= sum_v (sequentially) K_v[r] G_v[c]; K through the scalar cache,
+//                 G in registers, 16 N^2 bytes per CALL (chunks of kCallV corrections per pass).
+#include "ekf_kernels.hpp"
+
+namespace ekf {
+
+constexpr int kNcMax = 3 + 2 * kCallV;
+
+__device__ __forceinline__ void wave_sync_lds() {
+    // one wavefront: DS instructions of a wave execute in order, so only the COMPILER must not reorder across this point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// position of global index-5 entry k of correction v inside the core: {0, 1, 2, 3 + 2v, 4 + 2v}
+__device__ __forceinline__ constexpr int core5(int k, int v) { return k < 3 ? k : 3 + 2 * v + (k - 3); }
+
+constexpr int kFactorThreads = 64 + 256;   // wave 0 = the core filter; 256 slice threads
+
+__global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, CallSrc src, double* __restrict__ Uall,
+                                                                 double* __restrict__ Vall, int* __restrict__ cnt_out,
+                                                                 double* __restrict__ state_out) {
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int N = pv.N, ld = pv.ld;
+    const double* __restrict__ Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    const double* __restrict__ st = pv.state + (size_t)b * ld;
+    double* __restrict__ so = state_out + (size_t)b * ld;
+    double* __restrict__ Ub = Uall + (size_t)b * 2 * kCallV * ld;
+    double* __restrict__ Vb = Vall + (size_t)b * 2 * kCallV * ld;
+
+    __shared__ int sh_lm[kCallV];
+    __shared__ int sh_cnt;
+    __shared__ double sh_zs[kCallV][2];
+    __shared__ double sh_pose[4];
+    __shared__ double sh_Cb[kNcMax][kNcMax + 1];
+    __shared__ double sh_sc[kNcMax + 1];
+    __shared__ double sh_tv[kCallV][16];                 // H[10], S^-1[4], nu[2] per correction
+    __shared__ double sh_Kc[kCallV][kNcMax][2];          // K_v on the core rows
+    __shared__ double sh_Gc[kCallV][2][kNcMax + 1];      // G_v on the core columns
+
+    // ---- which corrections: [v0, v0 + vcount) of this filter's call ----
+    if (tid < kCallV) {
+        int lm = -1;
+        double sx = 0.0, sy = 0.0;
+        const int v = src.v0 + tid;
+        if (tid < src.vcount) {
+            if (src.mode == SRC_INLINE) {
+                lm = src.inl_lm[tid];
+                sx = src.inl_xy[tid][0];
+                sy = src.inl_xy[tid][1];
+            } else if (src.mode == SRC_SENSOR_VECTOR) {
+                if (v < src.vlist[0]) {
+                    lm = src.vlist[1 + v];
+                    sx = src.sensor[(size_t)b * 2 * pv.n + 2 * lm];
+                    sy = src.sensor[(size_t)b * 2 * pv.n + 2 * lm + 1];
+                }
+            } else if (v < src.vmax) {
+                const size_t slot = (size_t)b * src.vmax + v;
+                lm = src.lm_idx[slot];
+                if (lm >= 0) { sx = src.z_xy[slot * 2]; sy = src.z_xy[slot * 2 + 1]; }
+            }
+        }
+        if (lm >= pv.n) lm = -1;
+        sh_lm[tid] = lm;
+        sh_zs[tid][0] = sx; sh_zs[tid][1] = sy;
+    }
+    if (tid >= 64 && tid < 67) {   // the pose every correction of the call uses: captured ONCE (:109-111)
+        const int k = tid - 64;
+        sh_pose[k] = src.fresh_pose ? st[k] : pv.snap[(size_t)b * 4 + k];
+    }
+    __syncthreads();
+    if (tid == 0) {                // landmarks are listed in ascending order and -1 padded: the count is the leading run
+        int c = 0;
+        while (c < kCallV && sh_lm[c] >= 0) c++;
+        sh_cnt = c;
+        if (blockIdx.x == 0) {
+            cnt_out[b] = c;
+            if (src.fresh_pose) { double* sn = pv.snap + (size_t)b * 4; sn[0] = sh_pose[0]; sn[1] = sh_pose[1]; sn[2] = sh_pose[2]; }
+            CorrRec rc;
+            rc.nu0 = 0.0; rc.nu1 = 0.0; rc.active = c > 0; rc.lm = c > 0 ? sh_lm[c - 1] : -1; rc.n_active = 0; rc.pad = 0;
+            pv.rec[b] = rc;
+            for (int v = 0; v < c; v++) touch_landmark(pv, b, sh_lm[v]);
+        }
+    }
+    __syncthreads();
+    const int cnt = sh_cnt;
+    const int Nc = 3 + 2 * cnt;
+    auto cidx = [&](int j) { return j < 3 ? j : 3 + 2 * sh_lm[(j - 3) >> 1] + ((j - 3) & 1); };
+
+    // ---- panels: slice thread s carries column i of Sigma[C, :] and row i of Sigma[:, C], i = slice base + s ----
+    const int s = tid - 64;
+    const int i = blockIdx.x * 256 + s;
+    const bool slice = tid >= 64;
+    const bool live = slice && i < N;
+    double Rcol[kNcMax], Crow[kNcMax], st_i = 0.0;
+#pragma unroll
+    for (int j = 0; j < kNcMax; j++) { Rcol[j] = 0.0; Crow[j] = 0.0; }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < kNcMax; j++)
+            if (j < Nc) {
+                const int cj = cidx(j);
+                Rcol[j] = Sg[(size_t)cj * ld + i];   // coalesced across the slice
+                Crow[j] = Sg[(size_t)i * ld + cj];   // one or two sectors of row i per landmark
+            }
+        st_i = st[i];
+    }
+    // ---- core block and core state (wave 0) ----
+    if (!slice) {
+        for (int e = lane; e < Nc * Nc; e += 64) {
+            const int j = e / Nc, c = e - j * Nc;
+            sh_Cb[j][c] = Sg[(size_t)cidx(j) * ld + cidx(c)];
+        }
+        if (lane < Nc) sh_sc[lane] = st[cidx(lane)];
+        // factors of unused core rows are exact zeros (the slices run their loops to kNcMax)
+        for (int e = lane; e < kCallV * kNcMax; e += 64) { sh_Kc[e / kNcMax][e % kNcMax][0] = 0.0; sh_Kc[e / kNcMax][e % kNcMax][1] = 0.0; }
+        for (int e = lane; e < kCallV * (kNcMax + 1); e += 64) { sh_Gc[e / (kNcMax + 1)][0][e % (kNcMax + 1)] = 0.0; sh_Gc[e / (kNcMax + 1)][1][e % (kNcMax + 1)] = 0.0; }
+    }
+    const double theta = sh_pose[0], x = sh_pose[1], y = sh_pose[2];
+    __syncthreads();
+
+    // ---- step t: wave 0 runs correction t of the core filter while the slices apply correction t - 1 ----
+#pragma unroll
+    for (int t = 0; t <= kCallV; t++) {
+      if (t <= cnt) {   // uniform (no break: the loop must unroll so that the panel registers are indexed statically)
+        if (!slice) {
+            if (t < cnt) {
+                const int v = t;
+                auto s55 = [&](int k, int l) { return sh_Cb[core5(k, v)][core5(l, v)]; };
+                wave_terms(lane, sh_sc[3 + 2 * v], sh_sc[4 + 2 * v], sh_zs[v][0], sh_zs[v][1], theta, x, y, pv.p.r_meas, s55, true,
+                           &sh_tv[v][0], &sh_tv[v][10], &sh_tv[v][14]);
+                wave_sync_lds();
+                if (lane < Nc) {   // K_v and G_v on the core, lane = core row / core column
+                    double sht0 = 0.0, sht1 = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const double p = sh_Cb[lane][core5(k, v)];
+                        const double g = sh_Cb[core5(k, v)][lane];
+                        sht0 += p * sh_tv[v][k];
+                        sht1 += p * sh_tv[v][5 + k];
+                        g0 += sh_tv[v][k] * g;
+                        g1 += sh_tv[v][5 + k] * g;
+                    }
+                    sh_Kc[v][lane][0] = sht0 * sh_tv[v][10] + sht1 * sh_tv[v][12];   // :178
+                    sh_Kc[v][lane][1] = sht0 * sh_tv[v][11] + sht1 * sh_tv[v][13];
+                    sh_Gc[v][0][lane] = g0;
+                    sh_Gc[v][1][lane] = g1;
+                }
+                wave_sync_lds();
+                for (int e = lane; e < Nc * Nc; e += 64) {   // the core block's own rank-2 update (:191-192)
+                    const int j = e / Nc, c = e - j * Nc;
+                    sh_Cb[j][c] = sh_Cb[j][c] - (sh_Kc[v][j][0] * sh_Gc[v][0][c] + sh_Kc[v][j][1] * sh_Gc[v][1][c]);
+                }
+                if (lane < Nc) {                             // core state (:186-187)
+                    double sv = sh_sc[lane] + (sh_Kc[v][lane][0] * sh_tv[v][14] + sh_Kc[v][lane][1] * sh_tv[v][15]);
+                    if (lane == 0) sv = normalize_angle(sv);
+                    sh_sc[lane] = sv;
+                }
+                wave_sync_lds();
+            }
+        } else if (t >= 1) {
+            const int v = t - 1;
+            double H0[5], H1[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { H0[k] = sh_tv[v][k]; H1[k] = sh_tv[v][5 + k]; }
+            // G_v[i] = H_v Sigma[c5(v), i]   (rows of H*Sigma, ekf_slam.cpp:178)
+            double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const double g = Rcol[core5(k, v)];
+                g0 += H0[k] * g;
+                g1 += H1[k] * g;
+            }
+            // K_v[i] = Sigma[i, c5(v)] H_v^T S_v^-1
+            double sht0 = 0.0, sht1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const double p = Crow[core5(k, v)];
+                sht0 += p * H0[k];
+                sht1 += p * H1[k];
+            }
+            double k0 = sht0 * sh_tv[v][10] + sht1 * sh_tv[v][12];
+            double k1 = sht0 * sh_tv[v][11] + sht1 * sh_tv[v][13];
+            if (!live) { g0 = 0.0; g1 = 0.0; k0 = 0.0; k1 = 0.0; }   // pad entries of the factors stay exact zeros
+            if (i < ld) {
+                Vb[(size_t)(2 * v) * ld + i] = g0;
+                Vb[(size_t)(2 * v + 1) * ld + i] = g1;
+                Ub[(size_t)(2 * v) * ld + i] = k0;
+                Ub[(size_t)(2 * v + 1) * ld + i] = k1;
+            }
+            // the panels take the correction (same expression as every other element of Sigma)
+#pragma unroll
+            for (int j = 0; j < kNcMax; j++) {
+                Rcol[j] = Rcol[j] - (sh_Kc[v][j][0] * g0 + sh_Kc[v][j][1] * g1);
+                Crow[j] = Crow[j] - (k0 * sh_Gc[v][0][j] + k1 * sh_Gc[v][1][j]);
+            }
+            st_i = st_i + (k0 * sh_tv[v][14] + k1 * sh_tv[v][15]);   // :186
+            if (i == 0) st_i = normalize_angle(st_i);                 // :187
+        }
+        __syncthreads();
+      }
+    }
+    if (slice && i < ld) so[i] = live ? st_i : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming pass: every element takes the corrections of the call in order.  Same tiling as k_rank2 (strip of 256
+// double2 columns; rows in groups of UR with the next group's loads issued before this group's stores); a lane keeps
+// G_v of its two columns for all kCallV corrections in registers, K_v(r, :) is wave-uniform (scalar loads).
+// grid (strips, row blocks, B).
+// ---------------------------------------------------------------------------------------------
+template <int UR, bool NT>
+__global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, const double* __restrict__ Uall,
+                                                const double* __restrict__ Vall, const int* __restrict__ cnt_all, int N,
+                                                int ld, size_t sigma_stride, int rows_per_block) {
+    const int b = blockIdx.z;
+    const int cnt = cnt_all[b];
+    if (cnt <= 0) return;
+    const int ld2n = ld >> 1, ld2a = (N + 1) >> 1;
+    const int c2 = blockIdx.x * 256 + threadIdx.x;
+    const int row_begin = blockIdx.y * rows_per_block;
+    const int row_end = min(N, row_begin + rows_per_block);
+    if (row_begin >= N || c2 >= ld2a) return;
+    const double* __restrict__ Ub = Uall + (size_t)b * 2 * kCallV * ld;
+    const double2_t* __restrict__ Vb2 = reinterpret_cast<const double2_t*>(Vall + (size_t)b * 2 * kCallV * ld);
+    double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + c2;
+
+    double2_t g0[kCallV], g1[kCallV];
+#pragma unroll
+    for (int v = 0; v < kCallV; v++) {
+        g0[v] = double2_t{0.0, 0.0}; g1[v] = double2_t{0.0, 0.0};
+        if (v < cnt) { g0[v] = Vb2[(size_t)(2 * v) * ld2n + c2]; g1[v] = Vb2[(size_t)(2 * v + 1) * ld2n + c2]; }
+    }
+    auto load = [&](double2_t (&buf)[UR], int row) {
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            const double2_t* p = col + (size_t)min(row + u, row_end - 1) * ld2n;
+            if constexpr (NT) buf[u] = __builtin_nontemporal_load(p);
+            else buf[u] = *p;
+        }
+    };
+    auto finish = [&](double2_t (&buf)[UR], int row) {
+#pragma unroll
+        for (int v = 0; v < kCallV; v++) {
+            if (v < cnt) {   // uniform
+                const double* __restrict__ u0 = Ub + (size_t)(2 * v) * ld + row;   // wave-uniform -> scalar loads
+                const double* __restrict__ u1 = u0 + ld;
+#pragma unroll
+                for (int u = 0; u < UR; u++) {
+                    const double k0 = u0[u], k1 = u1[u];
+                    buf[u].x = buf[u].x - (k0 * g0[v].x + k1 * g1[v].x);
+                    buf[u].y = buf[u].y - (k0 * g0[v].y + k1 * g1[v].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UR; u++)
+            if (row + u < row_end) {
+                double2_t* p = col + (size_t)(row + u) * ld2n;
+                if constexpr (NT) __builtin_nontemporal_store(buf[u], p);
+                else *p = buf[u];
+            }
+    };
+    double2_t A[UR], Bf[UR];
+    int r = row_begin;
+    load(A, r);
+    while (r + UR < row_end) {
+        load(Bf, r + UR);
+        finish(A, r);
+        r += UR;
+        if (r + UR < row_end) {
+            load(A, r + UR);
+            finish(Bf, r);
+            r += UR;
+        } else {
+            finish(Bf, r);
+            return;
+        }
+    }
+    finish(A, r);
+}
+
+void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, double* V, int* cnt, double* state_out,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(k_call_factors, dim3((pv.ld + 255) / 256, pv.B), dim3(kFactorThreads), 0, s, pv, src, U, V, cnt,
+                       state_out);
+}
+
+void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, const Rank2Tuning& t,
+                   hipStream_t s) {
+    const size_t pool_bytes = (size_t)pv.B * pv.N * ((size_t)pv.N * sizeof(double));
+    const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
+    const int ld2a = (pv.N + 1) / 2;
+    const long long strips = (long long)pv.B * ((ld2a + 255) / 256);
+    int rows = t.rows_per_block > 0 ? t.rows_per_block : (strips * pv.N >= 256LL * 8 * 32 ? 32 : (strips * pv.N >= 256LL * 4 * 8 ? 8 : 4));
+    dim3 grid((ld2a + 255) / 256, (pv.N + rows - 1) / rows, pv.B);
+    if (rows >= 16) {
+        if (nt) hipLaunchKernelGGL((k_rank2v<8, true>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
+        else hipLaunchKernelGGL((k_rank2v<8, false>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
+    } else {
+        if (nt) hipLaunchKernelGGL((k_rank2v<4, true>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
+        else hipLaunchKernelGGL((k_rank2v<4, false>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
+    }
+}
+
+}  // namespace ekf

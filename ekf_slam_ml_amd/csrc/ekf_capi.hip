@@ -78,6 +78,7 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
     c.active_prefix = a.active_prefix;
     c.fused = a.fused;
     c.coop = a.coop;
+    c.call_fused = a.call_fused;
     if (a.coop_target != c.coop_target) {
         c.coop_target = a.coop_target;
         c.coop_R = ekf::coop_rows_per_wg(c.pv.N, c.cus, c.coop_target);
@@ -121,6 +122,45 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
             if (visible[i]) P.note_touched(i);
         return checked_launch();
     }
+    if (P.call_fused_ok() && !P.coop_ok()) {
+        // beyond the small-map path: the call is two launches whatever the number of visible landmarks -- the factor
+        // panels of all its corrections, then ONE read-modify-write pass over Sigma (ekf_callfused.hip); bit-identical
+        EKFC(P.ensure_callfused());
+        std::vector<int> vl(1, 0);
+        for (int i = 0; i < n; i++)
+            if (visible[i]) {
+                vl.push_back(i);
+                if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1;
+                P.note_touched(i);
+            }
+        const int V = (int)vl.size() - 1;
+        vl[0] = V;
+        ekf::CallSrc cs{};
+        const bool by_value = P.init_flag && V <= ekf::kCallV;   // the first call needs the whole sensor vector (:113-128)
+        if (by_value) {
+            cs.mode = ekf::SRC_INLINE;
+            for (int v = 0; v < ekf::kCallV; v++) {
+                cs.inl_lm[v] = v < V ? vl[1 + v] : -1;
+                cs.inl_xy[v][0] = v < V ? sensor_xy[2 * vl[1 + v]] : 0.0;
+                cs.inl_xy[v][1] = v < V ? sensor_xy[2 * vl[1 + v] + 1] : 0.0;
+            }
+        } else {
+            EKFC(P.upload2(P.call_in, sensor_xy, sizeof(double) * 2 * n, vl.data(), sizeof(int) * vl.size()));
+            cs.mode = ekf::SRC_SENSOR_VECTOR;
+            cs.sensor = P.call_in;
+            cs.vlist = reinterpret_cast<const int*>(P.call_in + 2 * (size_t)n);
+        }
+        EKFC(P.use());  // settles a deferred prediction()
+        if (!P.init_flag) ekf::launch_measure_begin(P.pv, P.call_in, 1, P.stream);   // first call: every landmark (:113-128)
+        P.init_flag = 1;
+        for (int v0 = 0; v0 < V; v0 += ekf::kCallV) {
+            cs.v0 = v0;
+            cs.vcount = V - v0 < ekf::kCallV ? V - v0 : ekf::kCallV;
+            cs.fresh_pose = v0 == 0;
+            EKFC(P.call_fused_pass(cs));
+        }
+        return checked_launch();
+    }
     if (P.coop_ok()) {
         // mid-size map (e.g. n = 200): the whole call -- and the prediction() before it -- in ONE launch with Sigma
         // resident in the LDS of a few dozen workgroups, one workgroup-to-all hand-off per visible landmark (ekf_coop.hip)
@@ -133,8 +173,18 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
                 P.note_touched(i);
             }
         vl[0] = (int)vl.size() - 1;
-        EKFC(P.upload2(P.coop_in, sensor_xy, sizeof(double) * 2 * n, vl.data(), sizeof(int) * vl.size()));
         ekf::CoopArgs ca{};
+        ca.inl_count = -1;
+        if (P.init_flag && vl[0] <= 8) {   // the readings of the visible landmarks travel by value: no host-to-device copy
+            ca.inl_count = vl[0];
+            for (int v = 0; v < vl[0]; v++) {
+                ca.inl_lm[v] = vl[1 + v];
+                ca.inl_xy[v][0] = sensor_xy[2 * vl[1 + v]];
+                ca.inl_xy[v][1] = sensor_xy[2 * vl[1 + v] + 1];
+            }
+        } else {
+            EKFC(P.upload2(P.coop_in, sensor_xy, sizeof(double) * 2 * n, vl.data(), sizeof(int) * vl.size()));
+        }
         ca.sensor = P.coop_in;
         ca.vlist = reinterpret_cast<const int*>(P.coop_in + 2 * (size_t)n);
         ca.xchg = P.coop_xchg;
@@ -389,6 +439,13 @@ ekf_status ekf_set_fused_correction(ekf_handle h, int enable) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     h->pool.fused = enable ? 1 : 0;
     h->pool.alt_synced = false;
+    return EKF_OK;
+}
+
+ekf_status ekf_set_call_fused(ekf_handle h, int enable) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    EKFC(h->pool.use());
+    h->pool.call_fused = enable ? 1 : 0;
     return EKF_OK;
 }
 

@@ -72,6 +72,13 @@ ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int non
     return EKF_OK;
 }
 
+ekf_status ekf_batch_set_call_fused(ekf_batch_handle hb, int enable) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    EKFC(hb->pool.use());
+    hb->pool.call_fused = enable ? 1 : 0;
+    return EKF_OK;
+}
+
 ekf_status ekf_batch_rank2_variant(ekf_batch_handle hb, int* group_rows, int* nontemporal, int* threads, int* rows_per_block) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
     ekf::rank2_variant(hb->pool.pv, hb->pool.tuning, group_rows, nontemporal, threads, rows_per_block);
@@ -140,6 +147,8 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
                 corrections += P.slot_active[(size_t)t * vmax + v];
             }
     const bool delayed = P.pend_cap > 0;
+    const bool callf = !delayed && P.call_fused_ok();
+    if (callf) EKFC(P.ensure_callfused());
     // worst-case number of covariance passes (rank-2 launches, or flushes in delayed mode) for the events
     const size_t max_passes = delayed ? launches / (size_t)(P.pend_cap / 2) + 2 : launches;
     hipEvent_t* ev = nullptr;
@@ -189,6 +198,23 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
             if (cand > P.pv.n) cand = P.pv.n;
             if (cand > P.touched_bound) P.touched_bound = cand;
         }
+        if (callf) {   // the whole call of every filter: factor panels + ONE streaming pass per kCallV log slots
+            int vtop = 0;
+            for (int v = 0; v < vmax; v++) if (P.slot_active[(size_t)t * vmax + v] > 0) vtop = v + 1;
+            ekf::CallSrc cs{};
+            cs.mode = ekf::SRC_COMPACT_LOG;
+            cs.lm_idx = src.lm_idx;
+            cs.z_xy = src.z_xy;
+            cs.vmax = vmax;
+            for (int v0 = 0; v0 < vtop; v0 += ekf::kCallV) {
+                cs.v0 = v0;
+                cs.vcount = vtop - v0 < ekf::kCallV ? vtop - v0 : ekf::kCallV;
+                cs.fresh_pose = 0;   // k_measure_begin has recorded the pose of the call
+                EKFC(P.call_fused_pass(cs, ev ? ev[2 * k] : nullptr, ev ? ev[2 * k + 1] : nullptr));
+                k++;
+            }
+            continue;
+        }
         for (int v = 0; v < vmax; v++) {
             if (P.slot_active[(size_t)t * vmax + v] == 0) continue;
             src.v = v;
@@ -227,7 +253,7 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
         // algorithmic bytes of one covariance pass: every filter's Sigma read + written once
         const double per_pass = 2.0 * sizeof(double) * (double)P.pv.N * (double)P.pv.N;
         stats->rank2_bytes_per_launch =
-            delayed ? per_pass * (double)B : (launches ? per_pass * (double)corrections / (double)launches : 0.0);
+            (delayed || callf) ? per_pass * (double)B : (launches ? per_pass * (double)corrections / (double)launches : 0.0);
     }
     return EKF_OK;
 }

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(THREADS) void k_coop_measure(PoolView pv, CoopArgs 
     }
     if (tid < R) {
         stl[tid] = tid < nr ? st[r0 + tid] : 0.0;
-        zs[tid] = a.sensor[min(r0 - 3 + tid, N - 4)];
+        if (a.inl_count < 0) zs[tid] = a.sensor[min(r0 - 3 + tid, N - 4)];
     }
     if (tid >= 64 && tid < 67) sh_pose[tid - 64] = st[tid - 64];
     if (a.has_twist && tid < 64) {
@@ -188,11 +188,12 @@ __global__ __launch_bounds__(THREADS) void k_coop_measure(PoolView pv, CoopArgs 
 
     COOP_TR(3);
     // ---- the visible landmarks in ascending order, :132-194 ----
-    const int V = a.vlist[0];
-    int lm_next = V > 0 ? a.vlist[1] : 0;
+    const bool inl = a.inl_count >= 0;
+    const int V = inl ? a.inl_count : a.vlist[0];
+    int lm_next = V > 0 ? (inl ? a.inl_lm[0] : a.vlist[1]) : 0;
     for (int v = 0; v < V; v++) {
         const int lm = lm_next;
-        if (v + 1 < V) lm_next = a.vlist[2 + v];   // (scalar load: arrives while this correction runs)
+        if (v + 1 < V) lm_next = inl ? a.inl_lm[v + 1] : a.vlist[2 + v];   // (scalar load: arrives while this correction runs)
         COOP_TR(4 + 6 * v);
         const int owner = (2 * lm) / R;
         double* slot = a.xchg + v * a.xstride;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(THREADS) void k_coop_measure(PoolView pv, CoopArgs 
             const int la = 2 * (lm - lm0);   // local row of 3 + 2 lm
             COOP_CY(50);
             if (tid < 64) {                  // wave 0: H, S^-1, nu with the STALE pose (:137-183), lane-parallel
-                const double sx = zs[la], sy = zs[la + 1];
+                const double sx = inl ? a.inl_xy[v][0] : zs[la], sy = inl ? a.inl_xy[v][1] : zs[la + 1];
                 auto s55 = [&](int k, int l) {
                     const double* rowk = k < 3 ? P + k * NS : T + (la + k - 3) * NS;
                     return rowk[idx5(l, lm)];
@@ -346,9 +347,10 @@ __global__ __launch_bounds__(THREADS) void k_coop_measure(PoolView pv, CoopArgs 
             double* sn = pv.snap;
             sn[0] = theta; sn[1] = x; sn[2] = y;
             CorrRec rc;
-            rc.nu0 = sh_nu[0]; rc.nu1 = sh_nu[1]; rc.active = V > 0; rc.lm = V > 0 ? a.vlist[V] : -1; rc.n_active = 0; rc.pad = 0;
+            rc.nu0 = sh_nu[0]; rc.nu1 = sh_nu[1]; rc.active = V > 0; rc.n_active = 0; rc.pad = 0;
+            rc.lm = V > 0 ? (inl ? a.inl_lm[V - 1] : a.vlist[V]) : -1;
             pv.rec[0] = rc;
-            for (int v = 0; v < V; v++) touch_landmark(pv, 0, a.vlist[1 + v]);
+            for (int v = 0; v < V; v++) touch_landmark(pv, 0, inl ? a.inl_lm[v] : a.vlist[1 + v]);
         }
     }
     COOP_TR(kCoopTraceSlots - 1);

@@ -351,6 +351,28 @@ void launch_pool_run_known(const PoolView& pv, const double* twist, const int* l
                            const double* init_xy, int vmax, int t0, int t1, int do_init, hipStream_t s);
 int small_max_dim();          // largest N = 3 + 2n the small path accepts
 hipError_t small_prepare();   // raises the kernel's dynamic-LDS limit (87 KB > 64 KB default)
+// ---- a whole measurement() call as two launches: factor panels + one streaming pass (ekf_callfused.hip) ----
+constexpr int kCallV = 8;          // corrections per pass (longer calls take several passes)
+struct CallSrc {
+    int mode;                      // SRC_SENSOR_VECTOR: vlist + sensor; SRC_COMPACT_LOG: lm_idx + z_xy of one log step
+    const double* sensor;          // [B][2n]
+    const int* vlist;              // [1 + V]: V, then the visible landmarks in ascending order (single filter)
+    const int* lm_idx;             // [B][vmax], ascending, -1 padded
+    const double* z_xy;            // [B][vmax][2]
+    int vmax;
+    int v0, vcount;                // this pass takes corrections [v0, v0 + vcount) of the call, vcount <= kCallV
+    int fresh_pose;                // 1: first pass of a call -- the pose is read from the state and recorded in snap
+    // SRC_INLINE (single filter, calls of <= kCallV visible landmarks): the landmarks and their readings travel BY VALUE
+    // in the kernel-argument segment -- no staging buffer, no host-to-device copy, no copy -> kernel dependency
+    int inl_lm[kCallV];
+    double inl_xy[kCallV][2];
+};
+enum : int { SRC_INLINE = 3 };
+// U, V: [B][2 * kCallV][ld] factor rows (K_v(:,0), K_v(:,1) / G_v(0,:), G_v(1,:)); cnt [B]: corrections of this pass
+void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, double* V, int* cnt, double* state_out,
+                         hipStream_t s);
+void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, const Rank2Tuning& t, hipStream_t s);
+
 // ---- one-launch prediction() + measurement() tick of a mid-size single filter, Sigma resident in LDS (ekf_coop.hip) ----
 struct CoopArgs {
     const double* sensor;          // [2n] sensor_reading
@@ -365,6 +387,9 @@ struct CoopArgs {
     double dtheta, dx;
     double* sigma_next;
     double* state_next;
+    int inl_count;                 // >= 0: the visible landmarks and their readings are given by value below (vlist, sensor unused)
+    int inl_lm[8];
+    double inl_xy[8][2];
     long long* trace;              // nullable: [workgroups][kCoopTraceSlots] wall-clock stamps (100 MHz) of lane 0
 };
 constexpr int kCoopTraceSlots = 64;

@@ -200,8 +200,43 @@ struct Pool {
         return EKF_OK;
     }
 
-    // One-launch prediction() + measurement() tick of a mid-size single filter with Sigma resident in LDS (ekf_coop.hip)
-    int coop = 1;            // ekf_set_cooperative_tick
+    // measurement() as two launches per call: factor panels + ONE streaming pass over Sigma (ekf_callfused.hip).
+    // Exact (bit-identical).  Default for single filters beyond the small-map path; opt-in for pools, whose eager
+    // per-landmark stream is the contract path the roofline is quoted on.
+    int call_fused = 0;
+    double* cf_U = nullptr;        // [B][2 kCallV][ld] (+ slack)
+    double* cf_V = nullptr;
+    int* cf_cnt = nullptr;         // [B]
+    double* cf_state = nullptr;    // [B][ld] out-of-place state of the factor kernel
+    double* call_in = nullptr;     // single filter: [2n] sensor_reading | [1 + n] ints: V, visible landmarks
+    bool call_fused_ok() const { return call_fused && pend_cap == 0 && !active_set && pv.n > 0 && pv.N > ekf::small_max_dim(); }
+    ekf_status ensure_callfused() {
+        if (!cf_U) {
+            const size_t cnt = (size_t)pv.B * 2 * ekf::kCallV * pv.ld + 64;
+            EKFC(dalloc(&cf_U, cnt));
+            EKFC(dalloc(&cf_V, cnt));
+            EKFC(dalloc(&cf_cnt, (size_t)pv.B));
+            EKFC(dalloc(&cf_state, (size_t)pv.B * pv.ld));
+        }
+        if (pv.B == 1 && !call_in) EKFC(dalloc(&call_in, (size_t)2 * pv.n + (size_t)(pv.n + 2 + 1) / 2));
+        return EKF_OK;
+    }
+    // corrections [.., ..) of one call for every filter: factor panels, state, then the streaming pass
+    ekf_status call_fused_pass(const ekf::CallSrc& src, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+        alt_synced = false;
+        ekf::launch_call_factors(pv, src, cf_U, cf_V, cf_cnt, cf_state, stream);
+        std::swap(pv.state, cf_state);
+        if (ev0) HIPC(hipEventRecord(ev0, stream));
+        EKFC(prof_begin(0));
+        ekf::launch_rank2v(pv, cf_U, cf_V, cf_cnt, tuning, stream);
+        EKFC(prof_end());
+        if (ev1) HIPC(hipEventRecord(ev1, stream));
+        return EKF_OK;
+    }
+
+    // One-launch prediction() + measurement() tick of a mid-size single filter with Sigma resident in LDS (ekf_coop.hip):
+    // opt-in (the two-launch call above is faster and needs no in-launch hand-offs)
+    int coop = 0;            // ekf_set_cooperative_tick
     int coop_R = 0;          // rows per workgroup; 0 = the map does not fit (or not a single filter)
     int coop_target = 0;     // requested number of workgroups (0 = default)
     int cus = 0;
@@ -405,6 +440,7 @@ struct Pool {
         pv.B = B;
         pv.sigma_stride = (size_t)pv.N * pv.ld;
         cus = prop.multiProcessorCount;
+        call_fused = B == 1 ? 1 : 0;
         coop_R = B == 1 ? ekf::coop_rows_per_wg(pv.N, cus, coop_target) : 0;
         EKFC(dalloc(&pv.sigma, (size_t)B * pv.sigma_stride));
         EKFC(dalloc(&pv.state, (size_t)B * pv.ld));
@@ -446,7 +482,7 @@ struct Pool {
                         pv.touch_count, scores, meas_dev,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, sigma_alt, state_fz, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
-                        coop_in, coop_xchg, coop_flags, coop_trace};
+                        coop_in, coop_xchg, coop_flags, coop_trace, cf_U, cf_V, cf_cnt, cf_state, call_in};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (coop_err) (void)hipHostFree(coop_err);

@@ -133,10 +133,20 @@ ekf_status ekf_batch_get_touched(ekf_batch_handle hb, int* counts_out);
  * LDS-resident launch instead of 2 launches per visible landmark; enable != 0 is the default.  Bit-identical
  * to the multi-kernel path. */
 ekf_status ekf_set_small_map_path(ekf_handle h, int enable);
+/* measurement() as TWO launches per call, whatever the number of visible landmarks (maps beyond the small-map path):
+ * the Kalman gains K_v and the rows H_v Sigma of ALL the call's corrections are obtained from two thin panels of Sigma
+ * (the rows and the columns of the pose and of the visible landmarks: O(V^2 N) work), then every element of Sigma takes
+ * its V rank-2 corrections, in order, in ONE read-modify-write pass: 16 N^2 bytes per CALL instead of per landmark, and
+ * still bit-identical to the per-landmark path (ekf_slam.cpp:132-194).  Calls with more than 8 visible landmarks take
+ * one pass per 8.  Default: on for a single filter; off for pools (ekf_batch_run_known), whose per-landmark stream is
+ * the contract path of the roofline figure -- switch it on there to halve (V = 2) the traffic of a step. */
+ekf_status ekf_set_call_fused(ekf_handle h, int enable);
+ekf_status ekf_batch_set_call_fused(ekf_batch_handle hb, int enable);
 /* Single filter, mid-size maps (104 < N = 3 + 2n, as long as N rows of Sigma spread over the device's CUs fit their
  * LDS: n up to about 700): ekf_predict + ekf_measure_known of one node tick run as ONE launch -- the rows of Sigma are
  * split over `workgroups` workgroups (0 = automatic, about 50; at most one per CU) that keep them in LDS for all the
- * visible landmarks of the call and exchange one 2 x N block per landmark inside the launch (enable != 0, default).
+ * visible landmarks of the call and exchange one 2 x N block per landmark inside the launch (enable != 0; default OFF:
+ * the two-launch call above is faster -- profiles/r02/coop_handoff_trace.txt).
  * ekf_predict then launches nothing by itself: the twist rides along with the next ekf_measure_known (any other call
  * in between makes the pending prediction happen first).  enable == 0: one launch per landmark (ekf_set_fused_correction).
  * Bit-identical either way. */

@@ -1,0 +1,143 @@
+"""-m gpu: measurement() as two launches per call (ekf_callfused.hip): the gains K_v and rows G_v = H_v Sigma of all
+the call's corrections from two thin panels of Sigma, then ONE read-modify-write pass in which every element takes its
+V rank-2 corrections in order.  Must be BIT-identical to the launch-per-landmark path (single filters and pools, ragged
+visible counts, calls longer than one pass, calls without any visible landmark) and agree with the CPU checker."""
+import numpy as np
+import pytest
+
+from ekf_slam_ml_amd import synth
+from parity import FP64_TOL, assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _replay(f, log, t0, t1):
+    for t in range(t0, t1):
+        sensor, vis = log.expand_step(t)
+        f.prediction(log.twist[t, 0])
+        f.measurement(sensor, vis)
+
+
+def _single(hip, n, call_fused):
+    f = hip.EKF_SLAM(n)
+    f.set_cooperative_tick(False)
+    f.set_call_fused(call_fused)
+    return f
+
+
+def test_call_fused_config1_bitwise_and_vs_checker(hip, oracle):
+    T = 40
+    log = synth.make_known_log(synth.config2(steps=T))
+    outs = []
+    for cf in (True, False):
+        f = _single(hip, 200, cf)
+        _replay(f, log, 0, 15)
+        g = f.clone()
+        f.close()
+        _replay(g, log, 15, T)
+        outs.append((g.state, g.cov))
+        g.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    o = oracle.OracleEKF(200, oracle.DENSE)
+    for t in range(10):
+        sensor, vis = log.expand_step(t)
+        o.prediction(*log.twist[t, 0]); o.measurement(sensor, vis)
+    f = _single(hip, 200, True)
+    _replay(f, log, 0, 10)
+    assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "call-fused measurement vs dense checker")
+    f.close()
+
+
+@pytest.mark.parametrize("n,vmax", [(60, 3), (60, 60), (101, 9), (333, 17), (700, 8), (1000, 11)])
+def test_call_fused_shapes_and_long_calls(hip, n, vmax):
+    """V from 0 to beyond one pass (8 corrections): several passes per call, the pose of the call is captured once."""
+    cfg = synth.SimConfig(n=n, steps=9, filters=1, seed=300 + n + vmax, half_extent=3.0, min_spacing=0.12,
+                          max_visible_dis=3.0 if vmax > 8 else 1.2, vmax=vmax)
+    log = synth.make_known_log(cfg)
+    counts = (log.lm_idx[:, 0] >= 0).sum(axis=1)
+    assert counts.max() >= min(vmax, 8)
+    res = []
+    for cf in (True, False):
+        f = _single(hip, n, cf)
+        _replay(f, log, 0, cfg.steps)
+        vis0 = np.zeros(n, dtype=np.uint8)
+        f.prediction((0.02, 0.01)); f.measurement(log.expand_step(3)[0], vis0)     # a call without visible landmarks
+        res.append((f.state, f.cov))
+        f.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.all(np.isfinite(res[0][1]))
+
+
+def test_call_fused_interleaved_with_association_and_snapshots(hip):
+    n = 150
+    cfg = synth.SimConfig(n=n, steps=20, filters=1, seed=78, half_extent=2.5, min_spacing=0.2, max_visible_dis=1.0, vmax=8)
+    log = synth.make_known_log(cfg)
+    res = []
+    for cf in (True, False):
+        f = _single(hip, n, cf)
+        for t in range(cfg.steps):
+            sensor, vis = log.expand_step(t)
+            f.prediction(log.twist[t, 0])
+            if t % 4 == 3:
+                k = np.ones(n, dtype=np.uint8)
+                f.data_association(log.z_xy[t, 0, :3], k)
+            else:
+                f.measurement(sensor, vis)
+            if t == 9:
+                st, cv = f.state, f.cov
+                f.state, f.cov = st, cv
+            if t == 13:
+                f.set_call_fused(not cf)
+            if t == 16:
+                f.set_call_fused(cf)
+        res.append((f.state, f.cov))
+        f.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("B,n,vmax", [(7, 400, 5), (5, 130, 12), (10, 1000, 2)])
+def test_call_fused_pool_bitwise_and_vs_checker(hip, oracle, B, n, vmax):
+    """Pools: ragged visible counts across filters (some filters sit a pass out), several passes per call, split runs."""
+    cfg = synth.SimConfig(n=n, steps=8, filters=B, seed=900 + n, half_extent=4.0, min_spacing=0.15,
+                          max_visible_dis=1.5 if vmax <= 5 else 3.0, vmax=vmax)
+    if n == 1000:
+        cfg = synth.config5(filters=B, steps=8, n=n)
+    log = synth.make_known_log(cfg)
+    counts = (log.lm_idx >= 0).sum(axis=2)
+    res = []
+    for cf in (True, False):
+        bt = hip.BatchEKF(B, n)
+        bt.set_call_fused(cf)
+        bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+        bt.run_known(0, 3)
+        st = bt.run_known(3, cfg.steps, time_kernels=True)
+        res.append(([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)], st))
+        bt.close()
+    for b in range(B):
+        assert np.array_equal(res[0][0][b], res[1][0][b]), f"filter {b} state"
+        assert np.array_equal(res[0][1][b], res[1][1][b]), f"filter {b} covariance"
+    assert res[0][2]["corrections"] == res[1][2]["corrections"] == int(counts[3:].sum())
+    assert res[0][2]["rank2_launches"] <= res[1][2]["rank2_launches"]
+    if n <= 400:
+        sto, cvo, _ = oracle.batch_run_known(log, oracle.STRUCTURED, want_cov=True, fast=False)
+        for b in range(B):
+            assert_parity(res[0][0][b], res[0][1][b], sto[b], cvo[b], FP64_TOL, f"call-fused pool filter {b} vs checker")
+
+
+def test_call_fused_pool_on_device_log_full_size(hip):
+    """BASELINE.json configs[4]'s shape at reduced B, inputs simulated on the device: one pass per step instead of two."""
+    cfg = synth.config5(filters=24, steps=7, n=1000)
+    world = synth.make_world(cfg.n, cfg.half_extent, cfg.min_spacing, cfg.world_seed)
+    res = []
+    for cf in (True, False):
+        bt = hip.BatchEKF(24, 1000)
+        bt.set_call_fused(cf)
+        bt.simulate_known_log(cfg, world)
+        st = bt.run_known(0, 7, time_kernels=True)
+        res.append((bt.checksum(), [bt.state(b) for b in (0, 11, 23)], bt.cov(23), st))
+        bt.close()
+    assert np.allclose(np.array(res[0][0]), np.array(res[1][0]), rtol=1e-12)   # (the digest sums with atomics: order varies)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[0][2], res[1][2])
+    assert res[0][3]["rank2_launches"] * 2 == res[1][3]["rank2_launches"]   # V = 2 corrections per call

@@ -8,7 +8,8 @@ from ekf_slam_ml_amd import capi, synth
 
 def run(n, log, inputs, steps, coop, wgs, profile=False):
     f = capi.EKF_SLAM(n)
-    f.set_cooperative_tick(coop, wgs)
+    f.set_call_fused(coop == "cf")
+    f.set_cooperative_tick(coop is True, wgs)
     for t in range(50):
         f.prediction(log.twist[t, 0]); f.measurement(*inputs[t])
     f.set_profiling(profile)
@@ -33,6 +34,11 @@ def case(n, cfg, wg_list):
     _, prof, _ = run(n, log, inputs, steps, False, 0, True)
     print(f"n={n} per-landmark launches : {(steps - 50) / dt:8.0f} steps/s {corr / dt:9.0f} corrections/s  "
           f"{dt / (steps - 50) * 1e6:7.1f} us/step  kernel avg {prof['stream_ms'] / prof['stream_launches'] * 1e3:6.2f} us x {prof['stream_launches']}", flush=True)
+    dt, _, st = run(n, log, inputs, steps, "cf", 0)
+    _, prof, _ = run(n, log, inputs, steps, "cf", 0, True)
+    print(f"n={n} two launches per call  : {(steps - 50) / dt:8.0f} steps/s {corr / dt:9.0f} corrections/s  "
+          f"{dt / (steps - 50) * 1e6:7.1f} us/step  stream kernel avg {prof['stream_ms'] / max(prof['stream_launches'], 1) * 1e3:6.2f} us x {prof['stream_launches']}"
+          f"  bit-identical {np.array_equal(st, ref)}", flush=True)
     for wgs in wg_list:
         dt, _, st = run(n, log, inputs, steps, True, wgs)
         _, prof, _ = run(n, log, inputs, steps, True, wgs, True)
@@ -54,9 +60,10 @@ def probe(n=200, wgs=0):
     sensor = world.reshape(-1).copy()
     for label, vis in (("V=0", np.zeros(n, dtype=np.uint8)), ("V=n", np.ones(n, dtype=np.uint8)),
                        ("V=8", np.r_[np.ones(8, dtype=np.uint8), np.zeros(n - 8, dtype=np.uint8)])):
-        for coop in (True, False):
+        for coop in (True, False, "cf"):
             f = capi.EKF_SLAM(n)
-            f.set_cooperative_tick(coop, wgs)
+            f.set_call_fused(coop == "cf")
+            f.set_cooperative_tick(coop is True, wgs)
             f.prediction((0.01, 0.02)); f.measurement(sensor, np.zeros(n, dtype=np.uint8))
             for _ in range(5):
                 f.prediction((0.01, 0.02)); f.measurement(sensor, vis)
@@ -83,6 +90,7 @@ def trace(n=200, V=6):
     vis = np.zeros(n, dtype=np.uint8)
     vis[rng.choice(n, size=V, replace=False)] = 1
     f = capi.EKF_SLAM(n)
+    f.set_cooperative_tick(True)
     f.prediction((0.01, 0.02)); f.measurement(sensor, np.zeros(n, dtype=np.uint8))
     f.cooperative_trace(True)
     for _ in range(6):
@@ -115,4 +123,7 @@ def trace(n=200, V=6):
     print(f"  loop done med {np.nanmedian(us[:, 62]):.2f} max {np.nanmax(us[:, 62]):.2f}; written back med {np.nanmedian(us[:, 63]):.2f} max {np.nanmax(us[:, 63]):.2f}")
 
 
-trace(200, 6)
+if "trace" in sys.argv: trace(200, 6)
+if "ab1000" in sys.argv:
+    c = synth.config3(steps=300)
+    case(1000, c, [])
