@@ -27,6 +27,7 @@
 namespace ekf {
 
 constexpr int kNcMax = 3 + 2 * kCallV;
+int rank2v_round_count(int vcount);
 
 __device__ __forceinline__ void wave_sync_lds() {
     // one wavefront: DS instructions of a wave execute in order, so only the COMPILER must not reorder across this point
@@ -42,7 +43,7 @@ constexpr int kFactorThreads = 64 + 256;   // wave 0 = the core filter; 256 slic
 
 __global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, CallSrc src, double* __restrict__ Uall,
                                                                  double* __restrict__ Vall, int* __restrict__ cnt_out,
-                                                                 double* __restrict__ state_out) {
+                                                                 double* __restrict__ state_out, int zero_upto) {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int N = pv.N, ld = pv.ld;
     const double* __restrict__ Sg = pv.sigma + (size_t)b * pv.sigma_stride;
@@ -223,22 +224,29 @@ __global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, Ca
         __syncthreads();
       }
     }
-    if (slice && i < ld) so[i] = live ? st_i : 0.0;
+    if (slice && i < ld) {
+        so[i] = live ? st_i : 0.0;
+        for (int v = cnt; v < zero_upto; v++) {   // rows of the pass this filter does not use: exact no-ops for k_rank2v
+            Vb[(size_t)(2 * v) * ld + i] = 0.0; Vb[(size_t)(2 * v + 1) * ld + i] = 0.0;
+            Ub[(size_t)(2 * v) * ld + i] = 0.0; Ub[(size_t)(2 * v + 1) * ld + i] = 0.0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Streaming pass: every element takes the corrections of the call in order.  Same tiling as k_rank2 (strip of 256
-// double2 columns; rows in groups of UR with the next group's loads issued before this group's stores); a lane keeps
-// G_v of its two columns for all kCallV corrections in registers, K_v(r, :) is wave-uniform (scalar loads).
-// grid (strips, row blocks, B).
+// Streaming pass: every element takes the corrections of the call in order.  Same tiling and pipeline as k_rank2
+// (strip of 256 double2 columns; rows in groups of UR through a ring of three register buffers, the loads of group g+1
+// issued before the stores of group g, no branch in the main loop); a lane keeps G_v of its two columns for the CNT
+// corrections of the pass in registers, K_v(r, :) is wave-uniform (scalar loads).  CNT is a template parameter (the
+// pass's correction count rounded up; k_call_factors zero-fills the factor rows a filter does not use, and a zero
+// factor is an exact no-op).  grid (strips, row blocks, B).
 // ---------------------------------------------------------------------------------------------
-template <int UR, bool NT>
+template <int UR, bool NT, int CNT>
 __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, const double* __restrict__ Uall,
                                                 const double* __restrict__ Vall, const int* __restrict__ cnt_all, int N,
                                                 int ld, size_t sigma_stride, int rows_per_block) {
     const int b = blockIdx.z;
-    const int cnt = cnt_all[b];
-    if (cnt <= 0) return;
+    if (cnt_all[b] <= 0) return;   // this filter has nothing to correct in this pass
     const int ld2n = ld >> 1, ld2a = (N + 1) >> 1;
     const int c2 = blockIdx.x * 256 + threadIdx.x;
     const int row_begin = blockIdx.y * rows_per_block;
@@ -248,81 +256,110 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
     const double2_t* __restrict__ Vb2 = reinterpret_cast<const double2_t*>(Vall + (size_t)b * 2 * kCallV * ld);
     double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + c2;
 
-    double2_t g0[kCallV], g1[kCallV];
+    double2_t g0[CNT], g1[CNT];
 #pragma unroll
-    for (int v = 0; v < kCallV; v++) {
-        g0[v] = double2_t{0.0, 0.0}; g1[v] = double2_t{0.0, 0.0};
-        if (v < cnt) { g0[v] = Vb2[(size_t)(2 * v) * ld2n + c2]; g1[v] = Vb2[(size_t)(2 * v + 1) * ld2n + c2]; }
-    }
-    auto load = [&](double2_t (&buf)[UR], int row) {
+    for (int v = 0; v < CNT; v++) { g0[v] = Vb2[(size_t)(2 * v) * ld2n + c2]; g1[v] = Vb2[(size_t)(2 * v + 1) * ld2n + c2]; }
+
+    auto load_group = [&](double2_t (&buf)[UR], int row) {
 #pragma unroll
         for (int u = 0; u < UR; u++) {
-            const double2_t* p = col + (size_t)min(row + u, row_end - 1) * ld2n;
+            const double2_t* p = col + (size_t)(row + u) * ld2n;
             if constexpr (NT) buf[u] = __builtin_nontemporal_load(p);
             else buf[u] = *p;
         }
     };
-    auto finish = [&](double2_t (&buf)[UR], int row) {
+    auto apply = [&](double2_t& x, int row) {
 #pragma unroll
-        for (int v = 0; v < kCallV; v++) {
-            if (v < cnt) {   // uniform
-                const double* __restrict__ u0 = Ub + (size_t)(2 * v) * ld + row;   // wave-uniform -> scalar loads
-                const double* __restrict__ u1 = u0 + ld;
-#pragma unroll
-                for (int u = 0; u < UR; u++) {
-                    const double k0 = u0[u], k1 = u1[u];
-                    buf[u].x = buf[u].x - (k0 * g0[v].x + k1 * g1[v].x);
-                    buf[u].y = buf[u].y - (k0 * g0[v].y + k1 * g1[v].y);
-                }
-            }
+        for (int v = 0; v < CNT; v++) {
+            const double k0 = Ub[(size_t)(2 * v) * ld + row], k1 = Ub[(size_t)(2 * v + 1) * ld + row];   // uniform -> s_load
+            x.x = x.x - (k0 * g0[v].x + k1 * g1[v].x);
+            x.y = x.y - (k0 * g0[v].y + k1 * g1[v].y);
         }
-#pragma unroll
-        for (int u = 0; u < UR; u++)
-            if (row + u < row_end) {
-                double2_t* p = col + (size_t)(row + u) * ld2n;
-                if constexpr (NT) __builtin_nontemporal_store(buf[u], p);
-                else *p = buf[u];
-            }
     };
-    double2_t A[UR], Bf[UR];
-    int r = row_begin;
-    load(A, r);
-    while (r + UR < row_end) {
-        load(Bf, r + UR);
-        finish(A, r);
-        r += UR;
-        if (r + UR < row_end) {
-            load(A, r + UR);
-            finish(Bf, r);
-            r += UR;
-        } else {
-            finish(Bf, r);
-            return;
+    auto finish_group = [&](double2_t (&buf)[UR], int row) {
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            apply(buf[u], row + u);
+            double2_t* p = col + (size_t)(row + u) * ld2n;
+            if constexpr (NT) __builtin_nontemporal_store(buf[u], p);
+            else *p = buf[u];
         }
+    };
+
+    const int nfull = (row_end - row_begin) / UR;  // uniform
+    int r = row_begin;
+    if (nfull > 0) {
+        double2_t A[UR], Bf[UR], Cf[UR];
+        load_group(A, r);
+        int g = 0;
+        for (; g + 3 < nfull; g += 3) {  // invariant: A holds group g; no branch inside
+            load_group(Bf, r + UR);
+            finish_group(A, r);
+            load_group(Cf, r + 2 * UR);
+            finish_group(Bf, r + UR);
+            load_group(A, r + 3 * UR);
+            finish_group(Cf, r + 2 * UR);
+            r += 3 * UR;
+        }
+        const int rem = nfull - g;  // 1, 2 or 3 groups left, A already loaded
+        if (rem == 1) {
+            finish_group(A, r);
+        } else if (rem == 2) {
+            load_group(Bf, r + UR);
+            finish_group(A, r);
+            finish_group(Bf, r + UR);
+        } else {
+            load_group(Bf, r + UR);
+            finish_group(A, r);
+            load_group(Cf, r + 2 * UR);
+            finish_group(Bf, r + UR);
+            finish_group(Cf, r + 2 * UR);
+        }
+        r += rem * UR;
     }
-    finish(A, r);
+    for (; r < row_end; r++) {   // < UR leftover rows of the last row block
+        double2_t x = col[(size_t)r * ld2n];
+        apply(x, r);
+        col[(size_t)r * ld2n] = x;
+    }
 }
 
 void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, double* V, int* cnt, double* state_out,
                          hipStream_t s) {
     hipLaunchKernelGGL(k_call_factors, dim3((pv.ld + 255) / 256, pv.B), dim3(kFactorThreads), 0, s, pv, src, U, V, cnt,
-                       state_out);
+                       state_out, rank2v_round_count(src.vcount));
 }
 
-void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, const Rank2Tuning& t,
+template <int UR, int CNT>
+static void launch_rank2v_c(const PoolView& pv, const double* U, const double* V, const int* cnt, bool nt, int rows, hipStream_t s) {
+    const int ld2a = (pv.N + 1) / 2;
+    dim3 grid((ld2a + 255) / 256, (pv.N + rows - 1) / rows, pv.B);
+    if (nt) hipLaunchKernelGGL((k_rank2v<UR, true, CNT>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
+    else hipLaunchKernelGGL((k_rank2v<UR, false, CNT>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
+}
+
+// corrections per pass are rounded up to an instantiated count; k_call_factors zero-fills up to it
+int rank2v_round_count(int vcount) { return vcount <= 1 ? 1 : vcount <= 2 ? 2 : vcount <= 4 ? 4 : vcount <= 6 ? 6 : kCallV; }
+
+void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, int vcount, const Rank2Tuning& t,
                    hipStream_t s) {
     const size_t pool_bytes = (size_t)pv.B * pv.N * ((size_t)pv.N * sizeof(double));
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
     const int ld2a = (pv.N + 1) / 2;
     const long long strips = (long long)pv.B * ((ld2a + 255) / 256);
-    int rows = t.rows_per_block > 0 ? t.rows_per_block : (strips * pv.N >= 256LL * 8 * 32 ? 32 : (strips * pv.N >= 256LL * 4 * 8 ? 8 : 4));
-    dim3 grid((ld2a + 255) / 256, (pv.N + rows - 1) / rows, pv.B);
-    if (rows >= 16) {
-        if (nt) hipLaunchKernelGGL((k_rank2v<8, true>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
-        else hipLaunchKernelGGL((k_rank2v<8, false>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
-    } else {
-        if (nt) hipLaunchKernelGGL((k_rank2v<4, true>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
-        else hipLaunchKernelGGL((k_rank2v<4, false>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
+    // measured (tools/callfused_sweep.py, B = 4096, n = 1000, V = 2): 64 rows per workgroup in 16-row groups streams at
+    // 6.47 TB/s (32 rows: 6.19) -- a workgroup first fetches its lanes' G values, which more rows amortise
+    const int rows = t.rows_per_block > 0 ? t.rows_per_block
+                                          : (strips * pv.N >= 256LL * 8 * 64 ? 64 : (strips * pv.N >= 256LL * 4 * 8 ? 8 : 4));
+    const int c = rank2v_round_count(vcount);
+    const bool big = rows >= 32;
+    const bool u16 = big && t.group_rows != 8;
+    switch (c) {
+        case 1: u16 ? launch_rank2v_c<16, 1>(pv, U, V, cnt, nt, rows, s) : big ? launch_rank2v_c<8, 1>(pv, U, V, cnt, nt, rows, s) : launch_rank2v_c<4, 1>(pv, U, V, cnt, nt, rows, s); break;
+        case 2: u16 ? launch_rank2v_c<16, 2>(pv, U, V, cnt, nt, rows, s) : big ? launch_rank2v_c<8, 2>(pv, U, V, cnt, nt, rows, s) : launch_rank2v_c<4, 2>(pv, U, V, cnt, nt, rows, s); break;
+        case 4: big ? launch_rank2v_c<8, 4>(pv, U, V, cnt, nt, rows, s) : launch_rank2v_c<4, 4>(pv, U, V, cnt, nt, rows, s); break;
+        case 6: big ? launch_rank2v_c<8, 6>(pv, U, V, cnt, nt, rows, s) : launch_rank2v_c<4, 6>(pv, U, V, cnt, nt, rows, s); break;
+        default: big ? launch_rank2v_c<8, kCallV>(pv, U, V, cnt, nt, rows, s) : launch_rank2v_c<4, kCallV>(pv, U, V, cnt, nt, rows, s); break;
     }
 }
 

@@ -371,7 +371,9 @@ enum : int { SRC_INLINE = 3 };
 // U, V: [B][2 * kCallV][ld] factor rows (K_v(:,0), K_v(:,1) / G_v(0,:), G_v(1,:)); cnt [B]: corrections of this pass
 void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, double* V, int* cnt, double* state_out,
                          hipStream_t s);
-void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, const Rank2Tuning& t, hipStream_t s);
+// vcount: corrections of the pass (the pool-wide maximum; filters with fewer have zero factor rows beyond theirs)
+void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, int vcount, const Rank2Tuning& t,
+                   hipStream_t s);
 
 // ---- one-launch prediction() + measurement() tick of a mid-size single filter, Sigma resident in LDS (ekf_coop.hip) ----
 struct CoopArgs {

@@ -228,7 +228,7 @@ struct Pool {
         std::swap(pv.state, cf_state);
         if (ev0) HIPC(hipEventRecord(ev0, stream));
         EKFC(prof_begin(0));
-        ekf::launch_rank2v(pv, cf_U, cf_V, cf_cnt, tuning, stream);
+        ekf::launch_rank2v(pv, cf_U, cf_V, cf_cnt, src.vcount, tuning, stream);
         EKFC(prof_end());
         if (ev1) HIPC(hipEventRecord(ev1, stream));
         return EKF_OK;
