@@ -225,7 +225,7 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
                 ekf::launch_gain(P.pv, src, P.stream);
                 if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
                 if (P.active_set) ekf::launch_rank2_active(P.pv, P.tuning, P.touched_bound, P.stream);
-                else ekf::launch_rank2(P.pv, P.tuning, P.stream);
+                else ekf::launch_rank2(P.pv, P.tuning, P.stream, true);
                 if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
                 k++;
             }

@@ -460,6 +460,118 @@ __global__ __launch_bounds__(TPB) void k_rank2(double* __restrict__ sigma, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row-PACKED form of the same update for pools whose rows do not fill the 256-lane strips (n = 200: 208 of 256 lanes
+// carry a column, 0.68 of peak): rows are contiguous in memory (ld doubles each, no gap), so P consecutive rows are ONE
+// contiguous virtual row of P * ld/2 double2 columns, and P is chosen so that the strips of 256 lanes tile it almost
+// exactly (n = 200: P = 6 -> 1248 of 1280 lanes).  A lane's slot s fixes its physical sub-row p = s / (ld/2) and its
+// column pair c2 = s % (ld/2), hence its two G values; going down the virtual rows it visits rows vr * P + p.  K(row, :)
+// is uniform except in a wavefront that straddles two sub-rows (at most two: ld/2 >= 64), where each lane selects one
+// of two scalar-loaded values.  Same expression per element as k_rank2 -> bit-identical.  Pad columns are streamed too
+// (their G is 0).  Full-width launches only: every K and G entry up to ld must be valid (known-association paths).
+// grid (ceil(P * ld/2 / 256), virtual row blocks, B).
+// ---------------------------------------------------------------------------------------------
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_rank2_packed(double* __restrict__ sigma, const double* __restrict__ Kg_all,
+                                                      const double* __restrict__ Gh_all, const CorrRec* __restrict__ rec,
+                                                      double* __restrict__ state, int N, int ld, size_t sigma_stride, int P,
+                                                      int vrows_per_block) {
+    const int b = blockIdx.z;
+    if (!rec[b].active) return;
+    const int ld2n = ld >> 1;
+    const int width = P * ld2n;                    // double2 columns of a virtual row
+    const int s = blockIdx.x * 256 + threadIdx.x;  // slot in the virtual row
+    const int nvfull = N / P;                      // virtual rows whose P sub-rows all exist
+    const int vr_begin = blockIdx.y * vrows_per_block;
+    if (vr_begin * P >= N) return;
+    const int vr_end = min(nvfull, vr_begin + vrows_per_block);
+    const double2_t* __restrict__ Kg = reinterpret_cast<const double2_t*>(Kg_all + (size_t)b * 2 * ld);
+
+    if (s < width) {
+        const int p = s / ld2n, c2 = s - p * ld2n;
+        // sub-rows of this wavefront: p_lo for its first lane, p_lo + 1 beyond the row boundary
+        const int wave_base = blockIdx.x * 256 + (threadIdx.x & ~63);
+        const int p_lo = __builtin_amdgcn_readfirstlane(wave_base / ld2n);
+        const bool hi = p != p_lo;
+        const int p_hi = min(p_lo + 1, P - 1);
+        const double2_t g0 = reinterpret_cast<const double2_t*>(Gh_all + (size_t)b * 2 * ld)[c2];
+        const double2_t g1 = reinterpret_cast<const double2_t*>(Gh_all + (size_t)b * 2 * ld + ld)[c2];
+        double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + s;
+
+        auto load_group = [&](double2_t (&buf)[U], int vr) {
+#pragma unroll
+            for (int u = 0; u < U; u++) buf[u] = ld2<NT>(col + (size_t)(vr + u) * width);
+        };
+        auto finish_group = [&](double2_t (&buf)[U], int vr) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double2_t klo = Kg[(vr + u) * P + p_lo], khi = Kg[(vr + u) * P + p_hi];  // uniform -> s_load
+                const double2_t k = hi ? khi : klo;
+                double2_t v = buf[u];
+                v.x = v.x - (k.x * g0.x + k.y * g1.x);
+                v.y = v.y - (k.x * g0.y + k.y * g1.y);
+                st2<NT>(col + (size_t)(vr + u) * width, v);
+            }
+        };
+        const int nfull = vr_end > vr_begin ? (vr_end - vr_begin) / U : 0;  // uniform
+        int r = vr_begin;
+        if (nfull > 0) {
+            double2_t A[U], Bf[U], Cf[U];
+            load_group(A, r);
+            int g = 0;
+            for (; g + 3 < nfull; g += 3) {  // invariant: A holds group g; no branch inside
+                load_group(Bf, r + U);
+                finish_group(A, r);
+                load_group(Cf, r + 2 * U);
+                finish_group(Bf, r + U);
+                load_group(A, r + 3 * U);
+                finish_group(Cf, r + 2 * U);
+                r += 3 * U;
+            }
+            const int rem = nfull - g;
+            if (rem == 1) {
+                finish_group(A, r);
+            } else if (rem == 2) {
+                load_group(Bf, r + U);
+                finish_group(A, r);
+                finish_group(Bf, r + U);
+            } else {
+                load_group(Bf, r + U);
+                finish_group(A, r);
+                load_group(Cf, r + 2 * U);
+                finish_group(Bf, r + U);
+                finish_group(Cf, r + 2 * U);
+            }
+            r += rem * U;
+        }
+        // leftover virtual rows of the block, and the ragged last virtual row of the matrix (sub-rows beyond N - 1 absent)
+        const int vr_last = min((N + P - 1) / P, vr_begin + vrows_per_block);
+        for (; r < vr_last; r++) {
+            const int row = r * P + p;
+            if (row < N) {
+                const double2_t k = Kg[row];
+                double2_t v = col[(size_t)r * width];
+                v.x = v.x - (k.x * g0.x + k.y * g1.x);
+                v.y = v.y - (k.x * g0.y + k.y * g1.y);
+                col[(size_t)r * width] = v;
+            }
+        }
+    }
+
+    // state = state + Ki*z_diff (:186); state(0) = normalize_angle(state(0)) (:187)
+    if (blockIdx.x == 0) {
+        const CorrRec rc = rec[b];
+        double* st = state + (size_t)b * ld;
+        const int row_begin = vr_begin * P, row_end = min(N, (vr_begin + vrows_per_block) * P);
+        for (int rr = row_begin + (int)threadIdx.x; rr < row_end; rr += 256) {
+            const double2_t k = Kg[rr];
+            double sv = st[rr] + (k.x * rc.nu0 + k.y * rc.nu1);
+            if (rr == 0) sv = normalize_angle(sv);
+            st[rr] = sv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Active-set form of the same update (opt-in, reported separately): only the rows of the touched set
 // -- pose rows and the rows of landmarks that have ever been corrected -- can have K != 0, so only they
 // are streamed: 2*8*N*(3 + 2*touched) bytes instead of 2*8*N^2.  Bit-identical to k_rank2 for finite
@@ -774,10 +886,46 @@ void rank2_variant(const PoolView& pv, const Rank2Tuning& t, int* u_out, int* nt
     if (rows_out) *rows_out = rows;
 }
 
-void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s) {
+// P > 1: the row-packed kernel serves this (full-width) view -- the smallest P <= 32 whose virtual rows fill the
+// 256-lane strips to >= 97 %; 1: the plain kernel (rows already fill their strips, rows shorter than a wavefront, or a
+// small pool that needs more workgroups than packing leaves)
+int rank2_packing(const PoolView& pv, const Rank2Tuning& t) {
+    const int ld2n = pv.ld / 2;
+    if (t.rows_per_block < 0) return 1;                       // tuning escape: rows_per_block < 0 forces the plain kernel
+    if (ld2n < 64) return 1;                                  // a wavefront may straddle at most two sub-rows
+    if ((pv.N + 15) / 16 * 16 != pv.ld) return 1;             // a prefix view: columns beyond it must stay untouched
+    auto util = [&](int P) { const long long w = (long long)P * ld2n; return (double)w / (double)((w + 255) / 256 * 256); };
+    if (util(1) >= 0.93) return 1;
+    if ((long long)pv.B * pv.N * ld2n < 256LL * 256 * 64) return 1;   // too little work for fat workgroups
+    for (int P = 2; P <= 32; P++)
+        if (util(P) >= 0.97) return P;
+    return 1;
+}
+
+void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s, bool full_width) {
     int u, nti, tpb, rows;
     rank2_variant(pv, t, &u, &nti, &tpb, &rows);
     const bool nt = nti != 0;
+    const int P = full_width ? rank2_packing(pv, t) : 1;
+    if (P > 1) {
+        const int ld2n = pv.ld / 2;
+        // measured (tools/rank2_width_sweep.py, profiles/r02/rank2_width_sweep.txt): ONE 8-row group per workgroup
+        // (n = 200, B = 16384: 6.26 TB/s = 0.78 of peak; 16 rows 0.73, 32 rows 0.64; the plain kernel 0.67)
+        const int vrows = t.rows_per_block > 0 ? t.rows_per_block : 8;
+        dim3 grid((P * ld2n + 255) / 256, ((pv.N + P - 1) / P + vrows - 1) / vrows, pv.B);
+        if (t.group_rows == 16) {
+            if (nt) hipLaunchKernelGGL((k_rank2_packed<16, true>), grid, dim3(256), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
+                                       pv.N, pv.ld, pv.sigma_stride, P, vrows);
+            else hipLaunchKernelGGL((k_rank2_packed<16, false>), grid, dim3(256), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
+                                    pv.N, pv.ld, pv.sigma_stride, P, vrows);
+        } else {
+            if (nt) hipLaunchKernelGGL((k_rank2_packed<8, true>), grid, dim3(256), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
+                                       pv.N, pv.ld, pv.sigma_stride, P, vrows);
+            else hipLaunchKernelGGL((k_rank2_packed<8, false>), grid, dim3(256), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
+                                    pv.N, pv.ld, pv.sigma_stride, P, vrows);
+        }
+        return;
+    }
     switch (u) {
         case 2: launch_rank2_u<2>(pv, rows, nt, s); break;
         case 4: launch_rank2_u<4>(pv, rows, nt, s); break;

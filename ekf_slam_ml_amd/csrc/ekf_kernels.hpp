@@ -291,7 +291,10 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
 // top of measurement(): pose snapshot (+ first-call landmark initialisation from init_xy [B][2n])
 void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init, hipStream_t s);
 void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s);
-void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s);
+// full_width: the caller guarantees valid K / G scratch over the whole row and column range (known-association paths),
+// which lets narrow maps take the row-packed kernel
+void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s, bool full_width = false);
+int rank2_packing(const PoolView& pv, const Rank2Tuning& t);
 // the k_rank2<U, NT, TPB> instantiation and rows per workgroup launch_rank2 takes for this view (report hook)
 void rank2_variant(const PoolView& pv, const Rank2Tuning& t, int* u, int* nontemporal, int* tpb, int* rows);
 // Same update restricted to the rows of the touched set (exact: every other row has K = 0).

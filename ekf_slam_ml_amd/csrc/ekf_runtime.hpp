@@ -349,7 +349,7 @@ struct Pool {
         ekf::launch_gain(view, src, stream);
         EKFC(prof_begin(0));
         if (active_set && active_N == 0) ekf::launch_rank2_active(pv, tuning, touched_bound, stream);
-        else ekf::launch_rank2(view, tuning, stream);
+        else ekf::launch_rank2(view, tuning, stream, active_N == 0 && src.mode != ekf::SRC_ASSOC);
         EKFC(prof_end());
         return EKF_OK;
     }

@@ -527,3 +527,23 @@ def test_device_normalize_angle_bit_exact(hip, oracle):
         return
     sub = np.concatenate([xs[:200], xs[-300:]])
     assert np.array_equal(hip.normalize_angles(sub), np.array([ref.normalize_angle(float(x)) for x in sub]))
+
+
+@pytest.mark.parametrize("n,B", [(200, 64), (100, 200), (60, 540), (333, 24)])
+def test_row_packed_rank2_is_bit_identical(hip, n, B):
+    """Pools of narrow maps take the row-packed rank-2 kernel (P rows side by side fill the 256-lane strips; ragged last
+    virtual row when N % P != 0, wavefronts straddling two sub-rows).  rows_per_block < 0 forces the plain kernel."""
+    cfg = synth.config5(filters=B, steps=7, n=n)
+    cfg.max_visible_dis, cfg.vmax = 1e9, 3
+    log = synth.make_known_log(cfg)
+    res = []
+    for rows in (0, -1):
+        bt = hip.BatchEKF(B, n)
+        bt.set_tuning(rows)
+        bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+        bt.run_known()
+        res.append(([bt.state(b) for b in (0, B // 2, B - 1)], [bt.cov(b) for b in (0, B // 2, B - 1)], bt.checksum()))
+        bt.close()
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert np.array_equal(a, b)
+    assert np.allclose(res[0][2], res[1][2], rtol=1e-12)
