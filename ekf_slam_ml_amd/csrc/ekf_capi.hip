@@ -261,9 +261,9 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         if (known[i]) known_count++; else break;
     }
     if (J == 0) return EKF_OK;
-    EKFC(P.flush());  // the scoring kernel reads Sigma directly
+    const bool delayed = P.pend_cap > 0;   // delayed mode: scores and gains against Sigma_base minus the pending pairs
     EKFC(P.ensure_meas_capacity(J));
-    if (P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && J <= ekf::kSmallInlineJ) {
+    if (!delayed && P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && J <= ekf::kSmallInlineJ) {
         // small map: the whole call (and the prediction() before it) in one LDS-resident launch, measurements by value
         P.alt_synced = false;
         ekf::SmallInlineMeas in;
@@ -275,7 +275,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         return associate_finish(P, known_count, J, known, assoc_out);
     }
     EKFC(P.upload(P.meas_dev, meas_xy, sizeof(double) * 2 * J));
-    if (P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && n <= 128) {
+    if (!delayed && P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && n <= 128) {
         // small map: scores, decisions and corrections of all J measurements in one LDS-resident launch
         P.alt_synced = false;
         ekf::launch_small_associate(P.pv, P.meas_dev, J, known_count, P.assoc_out_dev, P.pred_pending, P.pred_dth,
@@ -294,7 +294,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         int m = known_count + J < n ? known_count + J : n;
         if (P.touched_hwm > m) m = P.touched_hwm;
         const int Nb = 3 + 2 * m;
-        if (P.small_path && P.active_prefix && n > 0 && Nb <= ekf::small_max_dim()) {
+        if (!delayed && P.small_path && P.active_prefix && n > 0 && Nb <= ekf::small_max_dim()) {
             P.alt_synced = false;
             ekf::PoolView pva = P.pv;
             pva.N = Nb;
@@ -339,7 +339,9 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         }
         const ekf::MeasSrc ms{mj, 2, nullptr, 0};
         EKFC(P.prof_begin(1));
-        ekf::launch_maha(P.pv, ms, P.scores, -1, known_count + j < n ? known_count + j : n, P.stream);  // :300-309
+        const ekf::Pending pend = P.pending();
+        ekf::launch_maha(P.pv, ms, P.scores, -1, known_count + j < n ? known_count + j : n, P.stream,
+                         delayed ? &pend : nullptr);  // :300-309
         EKFC(P.prof_end());
         ekf::launch_assoc_decide(P.pv, ms, P.scores, P.assoc_out_dev, 0, j, nullptr, P.stream);    // :293-330
         src.meas = mj;
@@ -356,7 +358,7 @@ ekf_status ekf_maha_scores(ekf_handle h, double meas_x, double meas_y, int M, do
     if (M > P.pv.n) return fail(EKF_ERR_INVALID, "ekf_maha_scores: M exceeds the number of landmarks");
     if (M == 0) return EKF_OK;
     EKFC(P.use());
-    EKFC(P.flush());
+    EKFC(P.flush());   // (the parity hook reads the materialised covariance)
     EKFC(P.ensure_meas_capacity(1));
     const double m[2] = {meas_x, meas_y};
     EKFC(P.upload(P.meas_dev, m, sizeof(m)));

@@ -54,6 +54,11 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
             sx = src.z_xy[slot * 2];
             sy = src.z_xy[slot * 2 + 1];
         }
+    } else {  // data_association(): the decision of k_assoc_decide, :330-390
+        const AssocRec a = src.assoc[b];
+        lm = a.active ? a.lm : -1;
+        sx = src.meas[(size_t)b * src.meas_stride];
+        sy = src.meas[(size_t)b * src.meas_stride + 1];
     }
     if (lm < 0 || lm >= pv.n) {  // nothing to correct: carry the state over, append a zero pair
         if (r < ld) {

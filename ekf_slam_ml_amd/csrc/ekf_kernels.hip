@@ -643,7 +643,7 @@ __global__ void k_touch_all(PoolView pv) {
 // grid (ceil(M/4), B), 4 waves per workgroup; M = host bound of the known count (n without one).  With
 // ms.terms the wave also leaves H, S^-1 and nu of its landmark for the correction of the winner.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_maha(PoolView pv, MeasSrc ms, double* scores, int m_override) {
+__global__ __launch_bounds__(256) void k_maha(PoolView pv, MeasSrc ms, double* scores, int m_override, Pending pend) {
     const int b = blockIdx.y;
     if (ms.count && ms.j >= ms.count[b]) return;  // this filter has no measurement in this slot
     const double* meas = ms.xy + (size_t)b * ms.stride;
@@ -656,7 +656,17 @@ __global__ __launch_bounds__(256) void k_maha(PoolView pv, MeasSrc ms, double* s
     const double* st = pv.state + (size_t)b * ld;
 
     double v = 0.0;
-    if (lane < 25) v = Sg[(size_t)idx5(lane / 5, i) * ld + idx5(lane % 5, i)];
+    if (lane < 25) {
+        const int rr = idx5(lane / 5, i), cc = idx5(lane % 5, i);
+        v = Sg[(size_t)rr * ld + cc];
+        // delayed mode: the entry of the CURRENT covariance = base entry minus the pending pairs, in correction order
+        // (the arithmetic of k_gain_delayed's 5x5 block)
+        const double* Ub = pend.U + (size_t)b * pend.cap * ld;
+        const double* Vb = pend.V + (size_t)b * pend.cap * ld;
+        for (int j = 0; j < pend.count; j += 2)
+            v = __builtin_fma(-Ub[(size_t)(j + 1) * ld + rr], Vb[(size_t)(j + 1) * ld + cc],
+                              __builtin_fma(-Ub[(size_t)j * ld + rr], Vb[(size_t)j * ld + cc], v));
+    }
 
     MeasTerms m;  // fresh pose per score, :219-221
     measurement_terms(st[2 * i + 3], st[2 * i + 4], meas[0], meas[1], st[0], st[1], st[2], m);
@@ -949,12 +959,13 @@ void launch_touch_all(const PoolView& pv, hipStream_t s) {
 }
 
 void launch_maha(const PoolView& pv, const MeasSrc& ms, double* scores, int m_override, int m_bound,
-                 hipStream_t s) {
+                 hipStream_t s, const Pending* pend) {
     if (pv.n <= 0) return;
     int m = m_override >= 0 ? m_override : pv.n;  // landmarks that can be scored in this launch
     if (m_bound >= 0 && m_bound < m) m = m_bound;
     if (m <= 0) return;
-    hipLaunchKernelGGL(k_maha, dim3((m + 3) / 4, pv.B), dim3(256), 0, s, pv, ms, scores, m_override);
+    const Pending none{nullptr, nullptr, 0, 0, 0};
+    hipLaunchKernelGGL(k_maha, dim3((m + 3) / 4, pv.B), dim3(256), 0, s, pv, ms, scores, m_override, pend ? *pend : none);
 }
 
 void launch_assoc_begin(const PoolView& pv, const int* known_count_dev, int known_count_imm, hipStream_t s) {

@@ -312,8 +312,9 @@ void launch_correct_fused(const PoolView& pv, const CmdSrc& src, double* sigma_n
 // parity hook of normalize_angle (a8): out[i] = normalize_angle(in[i])
 void launch_normalize_angles(const double* in, int count, double* out, hipStream_t s);
 // m_bound >= 0: host-side upper bound of every filter's known_count (sizes the grid)
+// pend (nullable): delayed mode -- the scores are taken against Sigma_base minus the pending factor pairs
 void launch_maha(const PoolView& pv, const MeasSrc& ms, double* scores /*[B][n]*/, int m_override, int m_bound,
-                 hipStream_t s);
+                 hipStream_t s, const Pending* pend = nullptr);
 void launch_assoc_begin(const PoolView& pv, const int* known_count_dev, int known_count_imm, hipStream_t s);
 // decision for measurement j of every filter; assoc_out (nullable) gets [b*out_stride + j] = landmark or -1
 // corr_counter (nullable): += number of filters whose decision leads to a correction

@@ -326,7 +326,8 @@ struct Pool {
     // one landmark correction, eager (gain + covariance stream) or delayed (gain only, factors appended).
     // active_N > 0: the correction is exactly confined to the leading active_N block (data_association()).
     ekf_status correct(const ekf::CmdSrc& src, int active_N = 0) {
-        if (pend_cap > 0 && src.mode != ekf::SRC_ASSOC) {
+        if (pend_cap > 0 && (src.mode != ekf::SRC_ASSOC || pv.B == 1)) {
+            // (a measurement that data_association() drops appends a zero pair: the state buffers swap either way)
             if (pend_count + 2 > pend_cap) EKFC(flush());
             ekf::launch_gain_delayed(pv, src, pending(), state_alt, stream);
             std::swap(pv.state, state_alt);

@@ -316,8 +316,10 @@ ekf_status ekf_batch_mc_stats(ekf_batch_handle hb, int t, double out[6]);
  * (SURVEY.md section 8(f) f2): up to k corrections are kept as low-rank factors
  * (Sigma = Sigma_base - sum K_j (H Sigma)_j), the rows/columns a correction needs are rebuilt on the
  * fly, prediction() maps the factors, and Sigma is rewritten once per k corrections (and before any
- * call that reads it: get_cov, checksum, clone, data_association, maha_scores).  Same results to
- * rounding (tested at 1e-9); k is capped at 64.
+ * call that reads it: get_cov, checksum, clone, maha_scores; batch pools also before unknown-association runs).
+ * A single filter's data_association() stays delayed too: the Mahalanobis scores are taken against Sigma_base minus
+ * the pending pairs, the winner's correction is appended like any other.  Same results to rounding (tested at 1e-9);
+ * k is capped at 64.
  * symmetric_gather != 0 (delayed mode only): the gain step reads Sigma(c, r) where the reference reads
  * Sigma(r, c) for the five columns of Sigma*H^T -- a coalesced row read instead of a 16-KB-strided
  * column gather.  The reference never symmetrises Sigma, but (I - KH)Sigma keeps it symmetric to

@@ -136,3 +136,38 @@ def test_flush_grid_decode_for_any_batch_size(hip, B):
         bt.close()
     for b in range(B):
         assert_parity(res[1][b][0], res[1][b][1], res[0][b][0], res[0][b][1], 1e-11, f"B={B} filter {b}")
+
+
+@pytest.mark.parametrize("k", [4, 32])
+def test_delayed_data_association_without_flush(hip, oracle, k):
+    """data_association() in delayed mode (single filter): Mahalanobis scores against Sigma_base minus the pending pairs
+    (ekf_slam.cpp:217-276), decision and landmark initialisation as always, the winner's correction appended to the
+    factor store -- no flush in front of the call.  Decisions identical to the checker, state / covariance within 1e-9;
+    known-association calls are mixed in so that pending pairs of both kinds coexist."""
+    n, T = 120, 40
+    cfg = synth.SimConfig(n=n, steps=T, filters=1, seed=2024, half_extent=3.0, min_spacing=0.35, max_visible_dis=1.1, vmax=6)
+    ulog = synth.make_unknown_log(cfg)
+    f, o = hip.EKF_SLAM(n), oracle.OracleEKF(n, oracle.STRUCTURED)
+    f.set_update_mode(k)
+    kf, ko = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    total = 0
+    for t in range(T):
+        J = int(ulog.count[t, 0])
+        m = ulog.meas_xy[t, 0, :J]
+        f.prediction(ulog.twist[t, 0]); o.prediction(*ulog.twist[t, 0])
+        a, b = f.data_association(m, kf), o.data_association(m, ko)
+        assert np.array_equal(a, b), f"step {t}: decisions differ"
+        assert np.array_equal(kf, ko)
+        total += int((a >= 0).sum())
+        if t % 7 == 3 and ko.sum() >= 2:   # a known-association call on two discovered landmarks in between
+            sensor = np.zeros(2 * n); vis = np.zeros(n, dtype=np.uint8)
+            for j in range(min(J, 2)):
+                if a[j] >= 0:
+                    sensor[2 * a[j]:2 * a[j] + 2] = m[j]; vis[a[j]] = 1
+            f.set_init_flag(1) if hasattr(f, "set_init_flag") else None
+            o.set_init_flag(1)
+            f.landmark_init_flag = True
+            f.measurement(sensor, vis); o.measurement(sensor, vis)
+    assert total > 60 and ko.sum() >= 6
+    assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, f"delayed association k={k}")
+    f.close()
