@@ -43,6 +43,7 @@ SYMBOLS = [
     "ekf_dense_launch_info", "ekf_batch_rank2_variant",
     "ekf_set_profiling", "ekf_get_profile", "ekf_batch_set_known_counts",
     "ekf_set_cooperative_tick", "ekf_cooperative_trace", "ekf_set_call_fused", "ekf_batch_set_call_fused",
+    "ekf_batch_set_step_fused",
 ]
 
 
@@ -184,6 +185,7 @@ def load():
         "ekf_set_cooperative_tick": [h, C.c_int, C.c_int],
         "ekf_set_call_fused": [h, C.c_int],
         "ekf_batch_set_call_fused": [h, C.c_int],
+        "ekf_batch_set_step_fused": [h, C.c_int],
         "ekf_cooperative_trace": [h, C.c_int, C.POINTER(C.c_longlong), _ip],
         "ekf_get_profile": [h, _dp, C.POINTER(C.c_longlong)],
     }
@@ -550,6 +552,10 @@ class BatchEKF:
     def set_call_fused(self, enable=True):
         """every measurement() call of the pool as factor panels + ONE pass over Sigma (exact; default off for pools)"""
         _check(self._lib.ekf_batch_set_call_fused(self._h, int(bool(enable))))
+
+    def set_step_fused(self, enable=True):
+        """unknown association beyond the LDS-resident path: one launch per step (default) / four per measurement slot"""
+        _check(self._lib.ekf_batch_set_step_fused(self._h, int(bool(enable))))
 
     def rank2_kernel(self):
         """name of the k_rank2 instantiation a full-width eager correction of this pool launches, + rows per workgroup"""

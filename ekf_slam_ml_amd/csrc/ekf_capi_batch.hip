@@ -72,6 +72,12 @@ ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int non
     return EKF_OK;
 }
 
+ekf_status ekf_batch_set_step_fused(ekf_batch_handle hb, int enable) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    hb->pool.step_fused = enable ? 1 : 0;
+    return EKF_OK;
+}
+
 ekf_status ekf_batch_set_call_fused(ekf_batch_handle hb, int enable) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
     EKFC(hb->pool.use());
@@ -373,6 +379,19 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
             if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
             ekf::launch_pool_associate(pva, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
                                        3 + 2 * P.touched_hwm, P.ulog_assoc + (size_t)t * B * jmax, P.corr_counter, P.stream);
+            if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
+            k++;
+            smax = 0;  // the step is done
+        }
+        if (smax > 0 && P.step_fused && jmax <= ekf::kCallV && P.pend_cap == 0) {
+            // any prefix size: the whole step of every filter in ONE launch, its covariance streamed once per step
+            // (ekf_stepfused.hip); bit-identical to the four launches per measurement slot below
+            EKFC(P.ensure_callfused());
+            if (Nstep > 3 + 2 * kc_max) kc_max = (Nstep - 3) / 2;
+            if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
+            ekf::launch_pool_step_unknown(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
+                                          P.active_prefix ? 3 + 2 * P.touched_hwm : P.pv.N, P.ulog_assoc + (size_t)t * B * jmax,
+                                          P.cf_U, P.cf_V, P.corr_counter, P.stream);
             if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
             k++;
             smax = 0;  // the step is done

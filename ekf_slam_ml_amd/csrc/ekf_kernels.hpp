@@ -379,6 +379,11 @@ void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, doub
 void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, int vcount, const Rank2Tuning& t,
                    hipStream_t s);
 
+// one step of an unknown-association log for every filter of a pool in ONE launch, any prefix size (ekf_stepfused.hip):
+// jmax <= kCallV readings per filter; U, V: [B][2 kCallV][ld] scratch for the step's factor pairs
+void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
+                              int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s);
+
 // ---- one-launch prediction() + measurement() tick of a mid-size single filter, Sigma resident in LDS (ekf_coop.hip) ----
 struct CoopArgs {
     const double* sensor;          // [2n] sensor_reading

@@ -204,6 +204,7 @@ struct Pool {
     // Exact (bit-identical).  Default for single filters beyond the small-map path; opt-in for pools, whose eager
     // per-landmark stream is the contract path the roofline is quoted on.
     int call_fused = 0;
+    int step_fused = 1;            // pools, unknown association beyond the LDS-resident path: one launch per step
     double* cf_U = nullptr;        // [B][2 kCallV][ld] (+ slack)
     double* cf_V = nullptr;
     int* cf_cnt = nullptr;         // [B]

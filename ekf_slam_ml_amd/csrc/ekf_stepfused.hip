@@ -1,0 +1,292 @@
+// ekf_stepfused.hip -- one STEP of the unknown-association node loop (data_association() of <= kCallV readings,
+// ekf_slam.cpp:278-402) for every filter of a pool in ONE launch, for discovered prefixes of ANY size: one workgroup per
+// filter, and the filter's covariance is streamed ONCE per step instead of once per reading.
+//
+// The LDS-resident step kernel (k_pool_associate, ekf_small.hip) stops at N_b = 104; beyond it a step used to be four
+// launches per measurement slot (k_maha, k_assoc_decide, k_gain, k_rank2), each streaming or gathering from every
+// filter's 32-MB slab.  Here the corrections of a step are kept as factor pairs (K_v, G_v) until the step ends --
+// the idea of ekf_callfused.hip applied to data_association, whose decisions are sequential:
+//   for every reading j of the filter, in order:
+//     scores      one landmark per thread: the 25 entries of Sigma[c5(i), c5(i)] are the stored (step-begin) entries
+//                 minus the pending pairs of this step, applied in order with the rank-2 kernel's own expression --
+//                 the values the per-reading path would have read; the fresh pose and landmark come from the state,
+//                 which IS updated after every reading (:219-221, :331-333)
+//     decision    lexicographic (d, i) minimum, the two gates, landmark initialisation (:293-330)
+//     gain        K = Sigma H^T S^-1 and G = H Sigma over the filter's prefix from the same reconstruction of the five
+//                 rows / columns; appended as pair `pc`; state += K nu (:376-385)
+//   then ONE pass over the prefix applies the pairs to every element in order: x <- (x - K_0 G_0) - K_1 G_1 ...
+// Everything is the arithmetic of k_maha / k_assoc_decide / k_gain / k_rank2 in the same order -> decisions, state and
+// covariance are bit-identical to the four-launch path (tests/test_gpu_batch_unknown.py).
+#include "ekf_kernels.hpp"
+
+#include <climits>
+
+namespace ekf {
+
+constexpr int kStepThreads = 512;
+
+__global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv, const double* __restrict__ meas_all,
+                                                                    const int* __restrict__ count, int jmax, int min_active,
+                                                                    int* __restrict__ assoc_out, double* __restrict__ Uall,
+                                                                    double* __restrict__ Vall,
+                                                                    unsigned long long* __restrict__ corr_counter) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int J = count ? count[b] : jmax;
+    if (J <= 0) return;  // uniform
+    const int n = pv.n, ld = pv.ld;
+    // (no __restrict__: the pairs and the state are written and re-read by this workgroup, ordered by its barriers)
+    double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    double* st = pv.state + (size_t)b * ld;
+    double* Ub = Uall + (size_t)b * 2 * kCallV * ld;
+    double* Vb = Vall + (size_t)b * 2 * kCallV * ld;
+    const double* meas = meas_all + (size_t)b * jmax * 2;
+    int* out = assoc_out + (size_t)b * jmax;
+
+    __shared__ double sh_d[kStepThreads / 64];
+    __shared__ int sh_i[kStepThreads / 64];
+    __shared__ int sh_M, sh_lm, sh_new, sh_applied;
+    __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
+    __shared__ double2_t sh_K[32][kCallV];   // K_v of a row block of the final pass
+    // pending pairs at the five indices c5 of the landmark in hand: [v][0..2] = pose rows / columns (kept up to date as
+    // pairs are appended), [v][3..4] = the winner's two rows / columns (fetched after the decision)
+    __shared__ double sh_K5[kCallV][5][2], sh_G5[kCallV][5][2];
+
+    const int kc0 = pv.assoc[b].known_count;
+    // the filter's active dimension for this step: rows / columns beyond it still hold constructor values, where K and G
+    // are exact zeros (landmarks are appended in discovery order, :318-327)
+    int Nb = 3 + 2 * min(n, kc0 + J);
+    if (min_active > Nb) Nb = min_active;
+    if (Nb > pv.N) Nb = pv.N;
+    if (tid == 0) { sh_M = kc0; sh_applied = 0; }
+    __syncthreads();
+
+    int pc = 0;  // pending pairs of this step (uniform)
+    for (int j = 0; j < J; j++) {  // :291 sequential, state-carrying
+        const double mx = meas[2 * j], my = meas[2 * j + 1];
+        const int M = sh_M;
+        const double theta = st[0], x = st[1], y = st[2];   // fresh pose per reading, :219-221 / :331-333
+        // ---- scores, :300-309: one landmark per thread; the thread keeps H, S^-1, nu of its best landmark ----
+        double best = pv.p.gate_new;  // :293
+        int bi = INT_MAX;
+        double bH[10], bSi[4], bnu[2];
+        for (int i = tid; i < M; i += kStepThreads) {
+            MeasTerms m;
+            measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, theta, x, y, m);
+            double S55[5][5], S[2][2], Si[2][2];
+            const int ia = 3 + 2 * i;
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+#pragma unroll
+                for (int l = 0; l < 5; l++) S55[k][l] = Sg[(size_t)idx5(k, i) * ld + idx5(l, i)];
+            // the entries as they stand NOW: minus the pending pairs of this step, in order (k_rank2's expression)
+            for (int v = 0; v < pc; v++) {
+                double kr[5][2], gc[5][2];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { kr[k][0] = sh_K5[v][k][0]; kr[k][1] = sh_K5[v][k][1]; gc[k][0] = sh_G5[v][k][0]; gc[k][1] = sh_G5[v][k][1]; }
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    kr[3 + q][0] = Ub[(size_t)(2 * v) * ld + ia + q]; kr[3 + q][1] = Ub[(size_t)(2 * v + 1) * ld + ia + q];
+                    gc[3 + q][0] = Vb[(size_t)(2 * v) * ld + ia + q]; gc[3 + q][1] = Vb[(size_t)(2 * v + 1) * ld + ia + q];
+                }
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+#pragma unroll
+                    for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
+            }
+            innovation_cov(S55, m.H, pv.p.r_meas, S);   // sums in the order of k_maha's shuffle folds
+            inv2(S, Si);
+            const double v0 = m.z0 - m.zh0, v1 = m.z1 - m.zh1;   // bearing NOT wrapped, :269
+            const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
+            const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
+            const double sc = t0 * v0 + t1 * v1;
+            if (sc < best) {   // :305-309 (ascending i within the thread: the first minimum is kept; NaN never wins)
+                best = sc; bi = i;
+#pragma unroll
+                for (int k = 0; k < 5; k++) { bH[k] = m.H[0][k]; bH[5 + k] = m.H[1][k]; }
+                bSi[0] = Si[0][0]; bSi[1] = Si[0][1]; bSi[2] = Si[1][0]; bSi[3] = Si[1][1];
+                bnu[0] = v0; bnu[1] = v1;
+            }
+        }
+        // lexicographic (d, i) minimum = the sequential scan's first strict minimum
+        double rd = best;
+        int ri = bi;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_down(rd, off, kWave);
+            const int oi = __shfl_down(ri, off, kWave);
+            if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
+        }
+        if ((tid & 63) == 0) { sh_d[tid >> 6] = rd; sh_i[tid >> 6] = ri; }
+        __syncthreads();
+        if (tid == 0) {   // :293-330 (k_assoc_decide)
+            for (int w = 1; w < kStepThreads / 64; w++)
+                if (sh_d[w] < rd || (sh_d[w] == rd && sh_i[w] < ri)) { rd = sh_d[w]; ri = sh_i[w]; }
+            const int idx = (ri == INT_MAX) ? M : ri;   // :294 min_maha_idx = known_count
+            int Mn = M, is_new = 0;
+            if (idx == M && idx < n) {                  // :318-327 new landmark
+                const double rr = sqrt(mx * mx + my * my);
+                const double phi = atan2(my, mx);
+                st[2 * idx + 3] = x + rr * cos(phi + theta);
+                st[2 * idx + 3 + 1] = y + rr * sin(phi + theta);
+                Mn = M + 1;
+                rd = 0.0;
+                is_new = 1;
+            }
+            const int active = (rd < pv.p.gate_update) && idx < n;   // :330
+            sh_M = Mn;
+            sh_lm = active ? idx : -1;
+            sh_new = is_new;
+            out[j] = sh_lm;
+            if (active) sh_applied++;
+        }
+        __syncthreads();
+        const int lm = sh_lm;
+        if (lm < 0) { __syncthreads(); continue; }   // dropped (uniform); the barrier keeps sh_lm stable for slow waves
+        if (tid < 4 * pc) {   // pending pairs at the winner's two rows / columns
+            const int v = tid >> 2, q = (tid >> 1) & 1, h = tid & 1;
+            sh_K5[v][3 + q][h] = Ub[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
+            sh_G5[v][3 + q][h] = Vb[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
+        }
+        __syncthreads();
+        // ---- H, S^-1, nu of the winner: from the thread that scored it, or built for a new landmark (:331-381) ----
+        if (sh_new) {
+            if (tid == 0) {
+                MeasTerms m;
+                measurement_terms(st[2 * lm + 3], st[2 * lm + 4], mx, my, theta, x, y, m);
+                double S55[5][5], S[2][2], Si[2][2];
+                for (int k = 0; k < 5; k++)
+                    for (int l = 0; l < 5; l++) {
+                        double xe = Sg[(size_t)idx5(k, lm) * ld + idx5(l, lm)];
+                        for (int v = 0; v < pc; v++) xe = xe - (sh_K5[v][k][0] * sh_G5[v][l][0] + sh_K5[v][k][1] * sh_G5[v][l][1]);
+                        S55[k][l] = xe;
+                    }
+                innovation_cov(S55, m.H, pv.p.r_meas, S);
+                inv2(S, Si);
+                for (int k = 0; k < 5; k++) { sh_H[k] = m.H[0][k]; sh_H[5 + k] = m.H[1][k]; }
+                sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
+                sh_nu[0] = m.z0 - m.zh0;
+                sh_nu[1] = normalize_angle(m.z1 - m.zh1);
+            }
+        } else if (bi == lm) {   // exactly one thread scored landmark lm
+#pragma unroll
+            for (int k = 0; k < 10; k++) sh_H[k] = bH[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) sh_Si[k] = bSi[k];
+            sh_nu[0] = bnu[0];
+            sh_nu[1] = normalize_angle(bnu[1]);   // :183 (the score used it unwrapped)
+        }
+        __syncthreads();
+        // ---- K = Sigma H^T S^-1, G = H Sigma over the prefix (k_gain), appended as pair pc; state += K nu ----
+        for (int r = tid; r < ld; r += kStepThreads) {
+            double k0 = 0.0, k1 = 0.0, g0 = 0.0, g1 = 0.0;
+            if (r < Nb) {
+                double p[5], g[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const int c = idx5(k, lm);
+                    p[k] = Sg[(size_t)r * ld + c];   // column gather (Sigma * H^T reads columns)
+                    g[k] = Sg[(size_t)c * ld + r];   // row gather    (H * Sigma reads rows)
+                }
+                for (int v = 0; v < pc; v++) {       // ... as they stand now: minus the pending pairs, in order
+                    const double kr0 = Ub[(size_t)(2 * v) * ld + r], kr1 = Ub[(size_t)(2 * v + 1) * ld + r];
+                    const double gr0 = Vb[(size_t)(2 * v) * ld + r], gr1 = Vb[(size_t)(2 * v + 1) * ld + r];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        p[k] = p[k] - (kr0 * sh_G5[v][k][0] + kr1 * sh_G5[v][k][1]);
+                        g[k] = g[k] - (sh_K5[v][k][0] * gr0 + sh_K5[v][k][1] * gr1);
+                    }
+                }
+                double sht0 = 0.0, sht1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    sht0 += p[k] * sh_H[k];
+                    sht1 += p[k] * sh_H[5 + k];
+                    g0 += sh_H[k] * g[k];
+                    g1 += sh_H[5 + k] * g[k];
+                }
+                k0 = sht0 * sh_Si[0] + sht1 * sh_Si[2];   // :178 / :376
+                k1 = sht0 * sh_Si[1] + sht1 * sh_Si[3];
+                double s = st[r] + (k0 * sh_nu[0] + k1 * sh_nu[1]);   // :384
+                if (r == 0) s = normalize_angle(s);                    // :385
+                st[r] = s;
+            }
+            // (the pair is read back by cur_entry only after the barrier; entries beyond the prefix are exact zeros)
+            Ub[(size_t)(2 * pc) * ld + r] = k0;
+            Ub[(size_t)(2 * pc + 1) * ld + r] = k1;
+            Vb[(size_t)(2 * pc) * ld + r] = g0;
+            Vb[(size_t)(2 * pc + 1) * ld + r] = g1;
+            if (r < 3) { sh_K5[pc][r][0] = k0; sh_K5[pc][r][1] = k1; sh_G5[pc][r][0] = g0; sh_G5[pc][r][1] = g1; }   // pose part of the new pair
+        }
+        pc++;
+        __threadfence_block();
+        __syncthreads();
+    }
+
+    // ---- ONE pass over the prefix: every element takes the step's corrections in order (k_rank2's expression) ----
+    if (pc > 0) {
+        const int ld2n = ld >> 1, ld2a = (Nb + 1) >> 1;
+        double2_t* S2 = reinterpret_cast<double2_t*>(Sg);
+        const double2_t* V2 = reinterpret_cast<const double2_t*>(Vb);
+        for (int c0 = 0; c0 < ld2a; c0 += kStepThreads) {
+            const int c2 = c0 + tid;
+            const bool col_live = c2 < ld2a;
+            double2_t g0[kCallV], g1[kCallV];
+#pragma unroll
+            for (int v = 0; v < kCallV; v++) {
+                g0[v] = double2_t{0.0, 0.0}; g1[v] = double2_t{0.0, 0.0};
+                if (v < pc && col_live) { g0[v] = V2[(size_t)(2 * v) * ld2n + c2]; g1[v] = V2[(size_t)(2 * v + 1) * ld2n + c2]; }
+            }
+            for (int rb = 0; rb < Nb; rb += 32) {
+                __syncthreads();   // the previous block's sh_K has been consumed
+                for (int e = tid; e < 32 * kCallV; e += kStepThreads) {
+                    const int rr = e / kCallV, v = e - rr * kCallV;
+                    const int row = rb + rr;
+                    double2_t kk{0.0, 0.0};
+                    if (v < pc && row < Nb) kk = double2_t{Ub[(size_t)(2 * v) * ld + row], Ub[(size_t)(2 * v + 1) * ld + row]};
+                    sh_K[rr][v] = kk;
+                }
+                __syncthreads();
+                if (col_live) {
+                    const int nrow = min(32, Nb - rb);
+                    for (int u0 = 0; u0 < nrow; u0 += 8) {
+                        double2_t xv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) xv[u] = S2[(size_t)min(rb + u0 + u, Nb - 1) * ld2n + c2];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+#pragma unroll
+                            for (int v = 0; v < kCallV; v++) {
+                                if (v < pc) {   // uniform
+                                    const double2_t kk = sh_K[u0 + u][v];
+                                    xv[u].x = xv[u].x - (kk.x * g0[v].x + kk.y * g1[v].x);
+                                    xv[u].y = xv[u].y - (kk.x * g0[v].y + kk.y * g1[v].y);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                            if (u0 + u < nrow) S2[(size_t)(rb + u0 + u) * ld2n + c2] = xv[u];
+                    }
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        AssocRec a;
+        a.known_count = sh_M; a.lm = sh_lm; a.active = sh_lm >= 0; a.pad = 0; a.best = 0.0;
+        pv.assoc[b] = a;
+        if (corr_counter && sh_applied) atomicAdd(corr_counter, (unsigned long long)sh_applied);
+        // touched-set bookkeeping (active-set mode): every landmark below the new known_count counts as touched
+        unsigned char* tf = pv.touch_flag + (size_t)b * pv.n;
+        for (int i = 0; i < sh_M && i < n; i++)
+            if (!tf[i]) { tf[i] = 1; pv.touch_list[(size_t)b * pv.n + pv.touch_count[b]] = i; pv.touch_count[b]++; }
+    }
+}
+
+void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
+                              int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s) {
+    hipLaunchKernelGGL(k_pool_step_unknown, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
+                       assoc_out, U, V, corr_counter);
+}
+
+}  // namespace ekf

@@ -35,6 +35,7 @@ def test_batch_unknown_vs_oracle(hip, oracle):
     for small in (False, True):  # four launches per measurement slot / one LDS-resident launch per step (N = 43)
         bt = hip.BatchEKF(B, n)
         bt.set_small_map_path(small)
+        bt.set_step_fused(False)
         bt.upload_unknown_log(log.twist, log.count, log.meas_xy)
         st = bt.run_unknown(0, T, time_kernels=True)
         dec, kc = bt.decisions(), bt.known_counts()
@@ -161,24 +162,28 @@ def test_batch_unknown_outgrows_the_small_path(hip, oracle):
         meas[t, 1, :len(ids1)] = grid[ids1] + rng.normal(0, 0.003, (len(ids1), 2))
     log = type("L", (), {"twist": twist, "count": count, "meas_xy": meas})
     snap = []
-    for small in (True, False):
+    for small, fused in ((True, False), (False, False), (True, True)):
         bt = hip.BatchEKF(B, n)
         bt.set_small_map_path(small)
+        bt.set_step_fused(fused)
         bt.upload_unknown_log(twist, count, meas)
         st = bt.run_unknown(0, 20)
         st2 = bt.run_unknown(20, T)
         launches = st["rank2_launches"] + st2["rank2_launches"]
-        if small:  # early steps took the one-launch form, late ones (known_count + readings > 50) could not
+        if fused:    # LDS-resident step kernel first, then the any-size step kernel: one launch per step throughout
+            assert launches == int((count.max(axis=1) > 0).sum())
+        elif small:  # early steps took the one-launch form, late ones (known_count + readings > 50) could not
             assert T < launches < int(count.max(axis=1).sum())
         else:
             assert launches == int(count.max(axis=1).sum())
         snap.append((bt.decisions().copy(), bt.known_counts().copy(), [bt.state(b) for b in range(B)],
                      [bt.cov(b) for b in range(B)]))
         bt.close()
-    assert np.array_equal(snap[0][0], snap[1][0]) and np.array_equal(snap[0][1], snap[1][1])
     assert snap[0][1].max() > 52  # N_b > 104: beyond the small path
-    for b in range(B):
-        assert np.array_equal(snap[0][2][b], snap[1][2][b]) and np.array_equal(snap[0][3][b], snap[1][3][b])
+    for other in snap[1:]:
+        assert np.array_equal(snap[0][0], other[0]) and np.array_equal(snap[0][1], other[1])
+        for b in range(B):
+            assert np.array_equal(snap[0][2][b], other[2][b]) and np.array_equal(snap[0][3][b], other[3][b])
     o, known, d = _oracle_replay(oracle, log, 0, n, 0, T)
     assert np.array_equal(snap[0][0][:, 0], d)
     assert_parity(snap[0][2][0], snap[0][3][0], o.state, o.cov, FP64_TOL, "outgrowing the small path")
@@ -271,3 +276,51 @@ def test_surveyed_map_then_unknown_association(hip, oracle):
         bt.close()
     for (s0, c0), (s1, c1) in zip(*snap):
         assert np.array_equal(s0, s1) and np.array_equal(c0, c1)
+
+
+@pytest.mark.parametrize("surveyed", [False, True])
+def test_step_fused_beyond_the_small_path(hip, oracle, surveyed):
+    """Prefixes beyond N_b = 104: one launch per step (ekf_stepfused.hip: scores / decision / gain against the stored
+    covariance minus the step's pending pairs, ONE pass over the prefix at the end of the step) against four launches per
+    measurement slot -- bit for bit -- and against the CPU checker (decisions identical, 1e-9)."""
+    n, B, T = 150, 4, 30
+    # a fast robot on a 1.7 m circle: new landmarks come into view every step, the discovered prefix passes 104 quickly
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=4242, half_extent=2.6, min_spacing=0.3, max_visible_dis=0.7, vmax=7,
+                          v_cmd=2.0, w_cmd=1.2)
+    log = synth.make_unknown_log(cfg)
+    assert len(set(log.count.reshape(-1).tolist())) > 2
+    world = log.world
+    rng = np.random.default_rng(11)
+    init = (world[None] + rng.normal(0.0, 0.005, size=(B, n, 2))).reshape(B, 2 * n)
+    lm0 = np.full((2, B, 1), -1, dtype=np.int32)
+    snap = []
+    for fused in (True, False):
+        bt = hip.BatchEKF(B, n)
+        bt.set_small_map_path(False)   # (the LDS-resident step kernel would take the steps whose prefix is still <= 104)
+        bt.set_step_fused(fused)
+        if surveyed:   # every landmark known from the start (first known-association call initialises all of them)
+            bt.upload_known_log(np.zeros((2, B, 2)), lm0, np.zeros((2, B, 1, 2)), init)
+            bt.run_known()
+            bt.set_known_counts(n)
+        bt.upload_unknown_log(log.twist, log.count, log.meas_xy)
+        bt.run_unknown(0, 11)
+        st = bt.run_unknown(11, T, time_kernels=True)
+        dec, kc = bt.decisions(), bt.known_counts()
+        snap.append((dec.copy(), kc.copy(), [bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)], st))
+        bt.close()
+    assert np.array_equal(snap[0][0], snap[1][0]) and np.array_equal(snap[0][1], snap[1][1])
+    for b in range(B):
+        assert np.array_equal(snap[0][2][b], snap[1][2][b]), f"filter {b} state"
+        assert np.array_equal(snap[0][3][b], snap[1][3][b]), f"filter {b} covariance"
+    assert snap[0][4]["corrections"] == snap[1][4]["corrections"] > 50
+    assert snap[0][4]["rank2_launches"] < snap[1][4]["rank2_launches"]   # one launch per step, not per slot
+    for b in (0, B - 1):
+        o = oracle.OracleEKF(n, oracle.STRUCTURED)
+        known = np.zeros(n, dtype=np.uint8)
+        if surveyed:
+            o.prediction(0.0, 0.0); o.measurement_compact(init[b], lm0[0, b], np.zeros((1, 2)))
+            o.prediction(0.0, 0.0); o.measurement_compact(init[b], lm0[1, b], np.zeros((1, 2)))
+            known[:] = 1
+        o, known, d = _oracle_replay(oracle, log, b, n, 0, T, o, known)
+        assert np.array_equal(snap[0][0][:, b], d), f"filter {b}: decisions differ from the checker"
+        assert_parity(snap[0][2][b], snap[0][3][b], o.state, o.cov, FP64_TOL, f"step-fused filter {b}")

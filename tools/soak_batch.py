@@ -26,6 +26,7 @@ for seed in range(N_SCEN):
             meas[t, b] = np.stack([c * d[:, 0] + s * d[:, 1], -s * d[:, 0] + c * d[:, 1]], axis=1) + rng.normal(0, 0.004, (J, 2))
     bt = hip.BatchEKF(B, n)
     bt.set_small_map_path(bool(rng.integers(0, 2)))
+    bt.set_step_fused(bool(rng.integers(0, 2)))
     bt.set_active_prefix(bool(rng.integers(0, 2)))
     bt.upload_unknown_log(twist, count, meas)
     cut = int(rng.integers(0, T + 1))
