@@ -12,13 +12,16 @@ pytestmark = pytest.mark.gpu
 
 def _scenario(hip, oracle, seed):
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(1, 91))
+    n = int(rng.integers(1, 91)) if seed % 4 else int(rng.integers(52, 140))   # every 4th scenario beyond the small-map path
     f, o = hip.EKF_SLAM(n), oracle.OracleEKF(n, oracle.DENSE)
     mode = int(rng.choice([0, 0, 3, 16]))
     f.set_update_mode(mode, symmetric_gather=False)
     f.set_small_map_path(bool(rng.integers(0, 2)))
     f.set_active_prefix(bool(rng.integers(0, 2)))
     f.set_fused_correction(bool(rng.integers(0, 2)))
+    rng2 = np.random.default_rng(seed + 7919)   # (a second stream: the scenarios of round 1 keep their inputs)
+    f.set_call_fused(bool(rng2.integers(0, 2)))                                   # two launches per measurement() call
+    f.set_cooperative_tick(bool(rng2.integers(0, 2)), int(rng2.choice([0, 3, 17, 64])))   # one-launch LDS-resident tick
     world = rng.uniform(-2.5, 2.5, size=(n, 2))
     world[np.hypot(world[:, 0], world[:, 1]) < 0.3] += 0.6          # keep landmarks off the start pose
     pose = np.zeros(3)                                              # true (theta, x, y)
@@ -27,6 +30,10 @@ def _scenario(hip, oracle, seed):
     for t in range(int(rng.integers(6, 22))):
         if rng.random() < 0.1:                          # live switches must not disturb the filter
             f.set_fused_correction(bool(rng.integers(0, 2)))
+        if rng2.random() < 0.1:
+            f.set_call_fused(bool(rng2.integers(0, 2)))
+        if rng2.random() < 0.1:
+            f.set_cooperative_tick(bool(rng2.integers(0, 2)), int(rng2.choice([0, 3, 17, 64])))
         if rng.random() < 0.05:
             mode = int(rng.choice([0, 3, 16]))
             f.set_update_mode(mode, symmetric_gather=False)
