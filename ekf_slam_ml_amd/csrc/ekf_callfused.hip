@@ -39,11 +39,21 @@ __device__ __forceinline__ void wave_sync_lds() {
 // position of global index-5 entry k of correction v inside the core: {0, 1, 2, 3 + 2v, 4 + 2v}
 __device__ __forceinline__ constexpr int core5(int k, int v) { return k < 3 ? k : 3 + 2 * v + (k - 3); }
 
-constexpr int kFactorThreads = 64 + 256;   // wave 0 = the core filter; 256 slice threads
+// wave 0 = the core filter; SLICE slice threads (256 for pools; 64 for a single filter, whose row gathers -- one or two
+// 64-B sectors per row and landmark, uncoalesced -- are then spread over 4x as many CUs)
 
-__global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, CallSrc src, double* __restrict__ Uall,
+// diagnostics: stamp slot k of row `who` (0: lane 0 of the control wave, 1: lane 0 of the first slice wave)
+#define CF_TR(who, k)                                                                                              \
+    do {                                                                                                           \
+        if (src.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 64 * (who) && (k) < kCoopTraceSlots)         \
+            src.trace[(who) * kCoopTraceSlots + (k)] = clock64();                                                  \
+    } while (0)
+
+template <int SLICE>
+__global__ __launch_bounds__(64 + SLICE) void k_call_factors(PoolView pv, CallSrc src, double* __restrict__ Uall,
                                                                  double* __restrict__ Vall, int* __restrict__ cnt_out,
                                                                  double* __restrict__ state_out, int zero_upto) {
+    constexpr int kFactorThreads = 64 + SLICE;
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int N = pv.N, ld = pv.ld;
     const double* __restrict__ Sg = pv.sigma + (size_t)b * pv.sigma_stride;
@@ -53,7 +63,7 @@ __global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, Ca
     double* __restrict__ Vb = Vall + (size_t)b * 2 * kCallV * ld;
 
     __shared__ int sh_lm[kCallV];
-    __shared__ int sh_cnt;
+    __shared__ int sh_cidx[kNcMax + 1];   // global index of core position j (positions beyond the call's core: 0)
     __shared__ double sh_zs[kCallV][2];
     __shared__ double sh_pose[4];
     __shared__ double sh_Cb[kNcMax][kNcMax + 1];
@@ -61,7 +71,9 @@ __global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, Ca
     __shared__ double sh_tv[kCallV][16];                 // H[10], S^-1[4], nu[2] per correction
     __shared__ double sh_Kc[kCallV][kNcMax][2];          // K_v on the core rows
     __shared__ double sh_Gc[kCallV][2][kNcMax + 1];      // G_v on the core columns
+    __shared__ double sh_pr[8];                          // folded prediction: a10, a20, u0, u1, u2
 
+    CF_TR(0, 0); CF_TR(1, 0);
     // ---- which corrections: [v0, v0 + vcount) of this filter's call ----
     if (tid < kCallV) {
         int lm = -1;
@@ -87,61 +99,175 @@ __global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, Ca
         if (lm >= pv.n) lm = -1;
         sh_lm[tid] = lm;
         sh_zs[tid][0] = sx; sh_zs[tid][1] = sy;
+        sh_cidx[3 + 2 * tid] = lm >= 0 ? 3 + 2 * lm : 0;
+        sh_cidx[4 + 2 * tid] = lm >= 0 ? 4 + 2 * lm : 0;
+        if (tid < 3) sh_cidx[tid] = tid;
     }
-    if (tid >= 64 && tid < 67) {   // the pose every correction of the call uses: captured ONCE (:109-111)
-        const int k = tid - 64;
-        sh_pose[k] = src.fresh_pose ? st[k] : pv.snap[(size_t)b * 4 + k];
-    }
-    __syncthreads();
-    if (tid == 0) {                // landmarks are listed in ascending order and -1 padded: the count is the leading run
-        int c = 0;
-        while (c < kCallV && sh_lm[c] >= 0) c++;
-        sh_cnt = c;
-        if (blockIdx.x == 0) {
-            cnt_out[b] = c;
-            if (src.fresh_pose) { double* sn = pv.snap + (size_t)b * 4; sn[0] = sh_pose[0]; sn[1] = sh_pose[1]; sn[2] = sh_pose[2]; }
-            CorrRec rc;
-            rc.nu0 = 0.0; rc.nu1 = 0.0; rc.active = c > 0; rc.lm = c > 0 ? sh_lm[c - 1] : -1; rc.n_active = 0; rc.pad = 0;
-            pv.rec[b] = rc;
-            for (int v = 0; v < c; v++) touch_landmark(pv, b, sh_lm[v]);
+    // the pose every correction of the call uses, captured ONCE (:109-111): the load flies with the gathers below
+    double pose_k = 0.0;
+    if (tid >= 64 && tid < 67) pose_k = src.fresh_pose ? st[tid - 64] : pv.snap[(size_t)b * 4 + tid - 64];
+    // a folded prediction(): its sines and cosines only need theta -- lanes 0 / 1 of the last slice wave evaluate
+    // sin and cos of theta and theta + dtheta (two calls deep instead of four) while the gathers are in flight
+    if (src.has_twist && tid >= kFactorThreads - 64) {
+        const double th = st[0];
+        const double arg = (lane & 1) ? th + src.dtheta : th;
+        const double sv = sin(arg), cv = cos(arg);
+        const double sin_t = lane_bcast(sv, 0), sin_td = lane_bcast(sv, 1), cos_t = lane_bcast(cv, 0), cos_td = lane_bcast(cv, 1);
+        if (lane == 0) {
+            const double dtheta = src.dtheta, dx = src.dx;
+            double u0, u1, u2, a10, a20;
+            if (fabs(dtheta) < pv.p.straight_eps) {  // :79-86
+                u0 = 0;
+                u1 = dx * cos_t;
+                u2 = dx * sin_t;
+                a10 = -dx * sin_t;
+                a20 = dx * cos_t;
+            } else {  // :88-94
+                u0 = dtheta;
+                u1 = -(dx / dtheta) * sin_t + (dx / dtheta) * sin_td;
+                u2 = (dx / dtheta) * cos_t - (dx / dtheta) * cos_td;
+                a10 = -(dx / dtheta) * cos_t + (dx / dtheta) * cos_td;
+                a20 = -(dx / dtheta) * sin_t + (dx / dtheta) * sin_td;
+            }
+            sh_pr[0] = a10; sh_pr[1] = a20; sh_pr[2] = u0; sh_pr[3] = u1; sh_pr[4] = u2;
+            if (blockIdx.x == 0) { src.pred_out[(size_t)b * 2] = a10; src.pred_out[(size_t)b * 2 + 1] = a20; }
         }
     }
     __syncthreads();
-    const int cnt = sh_cnt;
+    // landmarks are listed in ascending order and -1 padded: the count is the leading run.  Every wavefront derives it
+    // by itself from the list (one ballot): no second barrier, no serial scan on the critical path.
+    const unsigned long long miss = __ballot(lane >= kCallV || sh_lm[lane < kCallV ? lane : 0] < 0);
+    const int cnt = __builtin_ctzll(miss | (1ull << kCallV));
     const int Nc = 3 + 2 * cnt;
-    auto cidx = [&](int j) { return j < 3 ? j : 3 + 2 * sh_lm[(j - 3) >> 1] + ((j - 3) & 1); };
+    // bookkeeping (count for the streaming pass, pose record, correction record, touched set): the lanes of the LAST slice
+    // wave, in parallel, off the control wave's critical path
+    if (blockIdx.x == 0 && tid >= kFactorThreads - 64) {
+        if (lane == 8) cnt_out[b] = cnt;
+        if (lane == 10) {
+            CorrRec rc;
+            rc.nu0 = 0.0; rc.nu1 = 0.0; rc.active = cnt > 0; rc.lm = cnt > 0 ? sh_lm[cnt - 1] : -1; rc.n_active = 0; rc.pad = 0;
+            pv.rec[b] = rc;
+        }
+        if (lane < cnt) {   // first touches: one landmark per lane (the order of the touch list is irrelevant)
+            const int lm = sh_lm[lane];
+            unsigned char* tf = pv.touch_flag + (size_t)b * pv.n;
+            if (!tf[lm]) {
+                tf[lm] = 1;
+                const int slot = atomicAdd(&pv.touch_count[b], 1);
+                pv.touch_list[(size_t)b * pv.n + slot] = lm;
+            }
+        }
+    }
+    // global index of core position j (clamped to a valid one beyond Nc): the landmark list goes to registers first, so
+    // that every gather below has its address without a dependent LDS round trip and all of them are in flight together
+    int lmr[kCallV];
+#pragma unroll
+    for (int v = 0; v < kCallV; v++) lmr[v] = v < cnt ? sh_lm[v] : 0;
+    auto cidx = [&](int j) {   // j compile-time in the unrolled loops below
+        return j < 3 ? j : 3 + 2 * lmr[(j - 3) >> 1] + ((j - 3) & 1);
+    };
 
     // ---- panels: slice thread s carries column i of Sigma[C, :] and row i of Sigma[:, C], i = slice base + s ----
     const int s = tid - 64;
-    const int i = blockIdx.x * 256 + s;
+    const int i = blockIdx.x * SLICE + s;
     const bool slice = tid >= 64;
     const bool live = slice && i < N;
     double Rcol[kNcMax], Crow[kNcMax], st_i = 0.0;
+    if (slice) {
+        const int ic = live ? i : 0;
 #pragma unroll
-    for (int j = 0; j < kNcMax; j++) { Rcol[j] = 0.0; Crow[j] = 0.0; }
-    if (live) {
+        for (int j = 0; j < kNcMax; j++) {   // unconditional, clamped: 2 x 19 loads in flight, one round trip
+            const int cj = cidx(j);
+            Rcol[j] = Sg[(size_t)cj * ld + ic];   // coalesced across the slice
+            Crow[j] = Sg[(size_t)ic * ld + cj];   // one or two sectors of row i per landmark
+        }
+        st_i = st[ic];
 #pragma unroll
         for (int j = 0; j < kNcMax; j++)
-            if (j < Nc) {
-                const int cj = cidx(j);
-                Rcol[j] = Sg[(size_t)cj * ld + i];   // coalesced across the slice
-                Crow[j] = Sg[(size_t)i * ld + cj];   // one or two sectors of row i per landmark
-            }
-        st_i = st[i];
-    }
-    // ---- core block and core state (wave 0) ----
-    if (!slice) {
-        for (int e = lane; e < Nc * Nc; e += 64) {
-            const int j = e / Nc, c = e - j * Nc;
-            sh_Cb[j][c] = Sg[(size_t)cidx(j) * ld + cidx(c)];
+            if (!live || j >= Nc) { Rcol[j] = 0.0; Crow[j] = 0.0; }
+        if (!live) st_i = 0.0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kNcMax; j++) { Rcol[j] = 0.0; Crow[j] = 0.0; }
+        // ---- core block and core state (wave 0): lane = (row group, column), all gathers issued before the first store ----
+        constexpr int kRounds = (kNcMax * kNcMax + 63) / 64;
+        double cbv[kRounds];
+#pragma unroll
+        for (int q = 0; q < kRounds; q++) {
+            const int e = lane + 64 * q;
+            const int j = min(e / kNcMax, kNcMax - 1), c = e - (e / kNcMax) * kNcMax;   // compile-time divisor
+            cbv[q] = Sg[(size_t)sh_cidx[j] * ld + sh_cidx[c]];   // positions beyond Nc are clamped copies, never used
         }
-        if (lane < Nc) sh_sc[lane] = st[cidx(lane)];
+        const double scv = st[sh_cidx[lane < kNcMax ? lane : 0]];
+#pragma unroll
+        for (int q = 0; q < kRounds; q++) {
+            const int e = lane + 64 * q;
+            if (e < kNcMax * kNcMax) sh_Cb[e / kNcMax][e % kNcMax] = cbv[q];
+        }
+        if (lane < kNcMax) sh_sc[lane] = scv;
         // factors of unused core rows are exact zeros (the slices run their loops to kNcMax)
         for (int e = lane; e < kCallV * kNcMax; e += 64) { sh_Kc[e / kNcMax][e % kNcMax][0] = 0.0; sh_Kc[e / kNcMax][e % kNcMax][1] = 0.0; }
         for (int e = lane; e < kCallV * (kNcMax + 1); e += 64) { sh_Gc[e / (kNcMax + 1)][0][e % (kNcMax + 1)] = 0.0; sh_Gc[e / (kNcMax + 1)][1][e % (kNcMax + 1)] = 0.0; }
     }
-    const double theta = sh_pose[0], x = sh_pose[1], y = sh_pose[2];
+    if (tid >= 64 && tid < 67) {
+        // (with a folded prediction the pose of the call is the PREDICTED pose: theta is not wrapped, :99)
+        const double pk = src.has_twist ? pose_k + sh_pr[2 + tid - 64] : pose_k;
+        sh_pose[tid - 64] = pk;
+        if (blockIdx.x == 0 && src.fresh_pose) pv.snap[(size_t)b * 4 + tid - 64] = pk;
+    }
+    CF_TR(0, 1); CF_TR(1, 1);
     __syncthreads();
+    if (src.has_twist) {
+        // ---- prediction(), :101-102, on what this workgroup holds (the structured arithmetic of k_predict) ----
+        const double a10 = sh_pr[0], a20 = sh_pr[1];
+        if (!slice) {
+            // core block: rows / columns 1, 2 beyond the pose block, then the 3 x 3 block from its OLD values
+            double c33[3][3];
+            if (lane == 0)
+                for (int r = 0; r < 3; r++)
+                    for (int k = 0; k < 3; k++) c33[r][k] = sh_Cb[r][k];
+            if (lane >= 3 && lane < Nc) {
+                const int k = lane;
+                const double q0 = sh_Cb[0][k], q1 = sh_Cb[1][k], q2 = sh_Cb[2][k];
+                const double r0c = sh_Cb[k][0], r1c = sh_Cb[k][1], r2c = sh_Cb[k][2];
+                sh_Cb[1][k] = a10 * q0 + q1;
+                sh_Cb[2][k] = a20 * q0 + q2;
+                sh_Cb[k][1] = r0c * a10 + r1c;
+                sh_Cb[k][2] = r0c * a20 + r2c;
+            }
+            if (lane == 0) {
+                double Tm[3][3];
+                for (int k = 0; k < 3; k++) {
+                    Tm[0][k] = c33[0][k];
+                    Tm[1][k] = a10 * c33[0][k] + c33[1][k];
+                    Tm[2][k] = a20 * c33[0][k] + c33[2][k];
+                }
+                for (int r = 0; r < 3; r++) {
+                    sh_Cb[r][0] = Tm[r][0];
+                    sh_Cb[r][1] = Tm[r][0] * a10 + Tm[r][1];
+                    sh_Cb[r][2] = Tm[r][0] * a20 + Tm[r][2];
+                }
+                sh_Cb[0][0] += pv.p.q_pose;  // Q = diag(q,q,q,0...) :40-43
+                sh_Cb[1][1] += pv.p.q_pose;
+                sh_Cb[2][2] += pv.p.q_pose;
+            }
+            if (lane < 3) sh_sc[lane] = sh_sc[lane] + sh_pr[2 + lane];   // :99 (theta not wrapped)
+        } else if (live && i >= 3) {
+            Rcol[1] = a10 * Rcol[0] + Rcol[1];   // rows 1, 2 of column i
+            Rcol[2] = a20 * Rcol[0] + Rcol[2];
+            Crow[1] = Crow[0] * a10 + Crow[1];   // columns 1, 2 of row i
+            Crow[2] = Crow[0] * a20 + Crow[2];
+        }
+        __syncthreads();
+        if (live && i < 3) {   // pose rows / columns: they ARE rows / columns of the (now predicted) core block
+#pragma unroll
+            for (int j = 0; j < kNcMax; j++)
+                if (j < Nc) { Rcol[j] = sh_Cb[j][i]; Crow[j] = sh_Cb[i][j]; }
+            st_i = st_i + sh_pr[2 + i];
+        }
+    }
+    const double theta = sh_pose[0], x = sh_pose[1], y = sh_pose[2];
+    CF_TR(0, 2); CF_TR(1, 2);
 
     // ---- step t: wave 0 runs correction t of the core filter while the slices apply correction t - 1 ----
 #pragma unroll
@@ -154,6 +280,7 @@ __global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, Ca
                 wave_terms(lane, sh_sc[3 + 2 * v], sh_sc[4 + 2 * v], sh_zs[v][0], sh_zs[v][1], theta, x, y, pv.p.r_meas, s55, true,
                            &sh_tv[v][0], &sh_tv[v][10], &sh_tv[v][14]);
                 wave_sync_lds();
+                CF_TR(0, 3 + 5 * t);
                 if (lane < Nc) {   // K_v and G_v on the core, lane = core row / core column
                     double sht0 = 0.0, sht1 = 0.0, g0 = 0.0, g1 = 0.0;
 #pragma unroll
@@ -171,9 +298,14 @@ __global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, Ca
                     sh_Gc[v][1][lane] = g1;
                 }
                 wave_sync_lds();
-                for (int e = lane; e < Nc * Nc; e += 64) {   // the core block's own rank-2 update (:191-192)
-                    const int j = e / Nc, c = e - j * Nc;
-                    sh_Cb[j][c] = sh_Cb[j][c] - (sh_Kc[v][j][0] * sh_Gc[v][0][c] + sh_Kc[v][j][1] * sh_Gc[v][1][c]);
+                CF_TR(0, 4 + 5 * t);
+                // the core block's own rank-2 update (:191-192); compile-time divisor, positions beyond Nc hold zero factors
+#pragma unroll
+                for (int q = 0; q < (kNcMax * kNcMax + 63) / 64; q++) {
+                    const int e = lane + 64 * q;
+                    const int j = e / kNcMax, c = e - j * kNcMax;
+                    if (j < Nc && c < Nc)
+                        sh_Cb[j][c] = sh_Cb[j][c] - (sh_Kc[v][j][0] * sh_Gc[v][0][c] + sh_Kc[v][j][1] * sh_Gc[v][1][c]);
                 }
                 if (lane < Nc) {                             // core state (:186-187)
                     double sv = sh_sc[lane] + (sh_Kc[v][lane][0] * sh_tv[v][14] + sh_Kc[v][lane][1] * sh_tv[v][15]);
@@ -181,6 +313,7 @@ __global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, Ca
                     sh_sc[lane] = sv;
                 }
                 wave_sync_lds();
+                CF_TR(0, 5 + 5 * t);
             }
         } else if (t >= 1) {
             const int v = t - 1;
@@ -220,10 +353,14 @@ __global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, Ca
             }
             st_i = st_i + (k0 * sh_tv[v][14] + k1 * sh_tv[v][15]);   // :186
             if (i == 0) st_i = normalize_angle(st_i);                 // :187
+            CF_TR(1, 5 + 5 * t);
         }
+        CF_TR(0, 6 + 5 * t); CF_TR(1, 6 + 5 * t);
         __syncthreads();
+        CF_TR(0, 7 + 5 * t); CF_TR(1, 7 + 5 * t);
       }
     }
+    CF_TR(0, 60); CF_TR(1, 60);
     if (slice && i < ld) {
         so[i] = live ? st_i : 0.0;
         for (int v = cnt; v < zero_upto; v++) {   // rows of the pass this filter does not use: exact no-ops for k_rank2v
@@ -241,12 +378,19 @@ __global__ __launch_bounds__(kFactorThreads) void k_call_factors(PoolView pv, Ca
 // pass's correction count rounded up; k_call_factors zero-fills the factor rows a filter does not use, and a zero
 // factor is an exact no-op).  grid (strips, row blocks, B).
 // ---------------------------------------------------------------------------------------------
-template <int UR, bool NT, int CNT>
+// PRED: a prediction() is folded in front of the corrections (single filter): element (r, c) first becomes
+// (At Sigma At^T + Q)(r, c) -- rows 1, 2 take a_r * row 0, columns 1, 2 take column 0 * a_c, the 3 x 3 pose block its own
+// formula (the structured arithmetic of k_predict, operation for operation) -- all from values this lane or its wave
+// neighbours hold: row 0 sits in the same row group as rows 1, 2, column 0 in lane 0 of strip 0.
+template <int UR, bool NT, int CNT, bool PRED>
 __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, const double* __restrict__ Uall,
                                                 const double* __restrict__ Vall, const int* __restrict__ cnt_all, int N,
-                                                int ld, size_t sigma_stride, int rows_per_block) {
+                                                int ld, size_t sigma_stride, int rows_per_block,
+                                                const double* __restrict__ pred, double q_pose) {
     const int b = blockIdx.z;
     if (cnt_all[b] <= 0) return;   // this filter has nothing to correct in this pass
+    double a10 = 0.0, a20 = 0.0;
+    if constexpr (PRED) { a10 = pred[(size_t)b * 2]; a20 = pred[(size_t)b * 2 + 1]; }
     const int ld2n = ld >> 1, ld2a = (N + 1) >> 1;
     const int c2 = blockIdx.x * 256 + threadIdx.x;
     const int row_begin = blockIdx.y * rows_per_block;
@@ -276,7 +420,54 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
             x.y = x.y - (k0 * g0[v].y + k1 * g1[v].y);
         }
     };
+    // prediction of one row group held in registers (PRED only).  Strip 0: lane 0 holds columns (0, 1), lane 1 (2, 3).
+    auto predict_group = [&](double2_t (&buf)[UR], int row) {
+        if constexpr (PRED) {
+            const bool strip0 = blockIdx.x == 0 && threadIdx.x < 64;   // the wavefront that holds columns 0..3 (uniform)
+            if (row == 0) {   // (uniform) the group with rows 0, 1, 2: UR >= 4
+                const double2_t o0 = buf[0], o1 = buf[1], o2 = buf[2];
+                // rows 1, 2 beyond the pose block: a_r * row 0 + row r   (k_predict: a10 * s0 + s1)
+                buf[1].x = a10 * o0.x + o1.x; buf[1].y = a10 * o0.y + o1.y;
+                buf[2].x = a20 * o0.x + o2.x; buf[2].y = a20 * o0.y + o2.y;
+                if (strip0) {
+                    // the 3 x 3 block from its OLD values: c[r][k], columns 0, 1 in lane 0, column 2 in lane 1
+                    double c[3][3];
+                    c[0][0] = __shfl(o0.x, 0, kWave); c[0][1] = __shfl(o0.y, 0, kWave); c[0][2] = __shfl(o0.x, 1, kWave);
+                    c[1][0] = __shfl(o1.x, 0, kWave); c[1][1] = __shfl(o1.y, 0, kWave); c[1][2] = __shfl(o1.x, 1, kWave);
+                    c[2][0] = __shfl(o2.x, 0, kWave); c[2][1] = __shfl(o2.y, 0, kWave); c[2][2] = __shfl(o2.x, 1, kWave);
+                    double T[3][3], Sn[3][3];
+                    for (int k = 0; k < 3; k++) {
+                        T[0][k] = c[0][k];
+                        T[1][k] = a10 * c[0][k] + c[1][k];
+                        T[2][k] = a20 * c[0][k] + c[2][k];
+                    }
+                    for (int r = 0; r < 3; r++) {
+                        Sn[r][0] = T[r][0];
+                        Sn[r][1] = T[r][0] * a10 + T[r][1];
+                        Sn[r][2] = T[r][0] * a20 + T[r][2];
+                    }
+                    Sn[0][0] += q_pose; Sn[1][1] += q_pose; Sn[2][2] += q_pose;
+                    if (c2 == 0) {
+                        buf[0] = double2_t{Sn[0][0], Sn[0][1]}; buf[1] = double2_t{Sn[1][0], Sn[1][1]}; buf[2] = double2_t{Sn[2][0], Sn[2][1]};
+                    } else if (c2 == 1) {   // column 2 from the block; column 3 of rows 1, 2 was set above, row 0 is unchanged
+                        buf[0].x = Sn[0][2]; buf[1].x = Sn[1][2]; buf[2].x = Sn[2][2];
+                    }
+                }
+            }
+            if (strip0) {   // columns 1, 2 of the rows beyond the pose block: column 0 * a_c + column c   (k_predict: r0 * a10 + r1)
+#pragma unroll
+                for (int u = 0; u < UR; u++) {
+                    const double col0 = __shfl(buf[u].x, 0, kWave);   // the OLD column-0 entry (the prediction leaves it alone)
+                    if (row + u >= 3) {
+                        if (c2 == 0) buf[u].y = buf[u].x * a10 + buf[u].y;
+                        else if (c2 == 1) buf[u].x = col0 * a20 + buf[u].x;
+                    }
+                }
+            }
+        }
+    };
     auto finish_group = [&](double2_t (&buf)[UR], int row) {
+        predict_group(buf, row);
 #pragma unroll
         for (int u = 0; u < UR; u++) {
             apply(buf[u], row + u);
@@ -317,8 +508,15 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
         }
         r += rem * UR;
     }
-    for (; r < row_end; r++) {   // < UR leftover rows of the last row block
+    for (; r < row_end; r++) {   // < UR leftover rows of the last row block (never rows 0..2: N >= UR)
         double2_t x = col[(size_t)r * ld2n];
+        if constexpr (PRED) {
+            if (blockIdx.x == 0 && threadIdx.x < 64) {
+                const double col0 = __shfl(x.x, 0, kWave);
+                if (c2 == 0) x.y = x.x * a10 + x.y;
+                else if (c2 == 1) x.x = col0 * a20 + x.x;
+            }
+        }
         apply(x, r);
         col[(size_t)r * ld2n] = x;
     }
@@ -326,40 +524,53 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
 
 void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, double* V, int* cnt, double* state_out,
                          hipStream_t s) {
-    hipLaunchKernelGGL(k_call_factors, dim3((pv.ld + 255) / 256, pv.B), dim3(kFactorThreads), 0, s, pv, src, U, V, cnt,
-                       state_out, rank2v_round_count(src.vcount));
+    if ((long long)pv.B * ((pv.ld + 255) / 256) >= 128)
+        hipLaunchKernelGGL(k_call_factors<256>, dim3((pv.ld + 255) / 256, pv.B), dim3(64 + 256), 0, s, pv, src, U, V, cnt,
+                           state_out, rank2v_round_count(src.vcount));
+    else
+        hipLaunchKernelGGL(k_call_factors<64>, dim3((pv.ld + 63) / 64, pv.B), dim3(64 + 64), 0, s, pv, src, U, V, cnt,
+                           state_out, rank2v_round_count(src.vcount));
 }
 
 template <int UR, int CNT>
-static void launch_rank2v_c(const PoolView& pv, const double* U, const double* V, const int* cnt, bool nt, int rows, hipStream_t s) {
+static void launch_rank2v_c(const PoolView& pv, const double* U, const double* V, const int* cnt, bool nt, int rows, hipStream_t s,
+                            const double* pred) {
     const int ld2a = (pv.N + 1) / 2;
     dim3 grid((ld2a + 255) / 256, (pv.N + rows - 1) / rows, pv.B);
-    if (nt) hipLaunchKernelGGL((k_rank2v<UR, true, CNT>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
-    else hipLaunchKernelGGL((k_rank2v<UR, false, CNT>), grid, dim3(256), 0, s, pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows);
+#define EKF_R2V_ARGS pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows, pred, pv.p.q_pose
+    if (pred) {   // single filter with a folded prediction (small pool: temporal accesses)
+        hipLaunchKernelGGL((k_rank2v<UR, false, CNT, true>), grid, dim3(256), 0, s, EKF_R2V_ARGS);
+    } else if (nt) {
+        hipLaunchKernelGGL((k_rank2v<UR, true, CNT, false>), grid, dim3(256), 0, s, EKF_R2V_ARGS);
+    } else {
+        hipLaunchKernelGGL((k_rank2v<UR, false, CNT, false>), grid, dim3(256), 0, s, EKF_R2V_ARGS);
+    }
+#undef EKF_R2V_ARGS
 }
 
 // corrections per pass are rounded up to an instantiated count; k_call_factors zero-fills up to it
 int rank2v_round_count(int vcount) { return vcount <= 1 ? 1 : vcount <= 2 ? 2 : vcount <= 4 ? 4 : vcount <= 6 ? 6 : kCallV; }
 
 void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, int vcount, const Rank2Tuning& t,
-                   hipStream_t s) {
+                   hipStream_t s, const double* pred) {
     const size_t pool_bytes = (size_t)pv.B * pv.N * ((size_t)pv.N * sizeof(double));
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
     const int ld2a = (pv.N + 1) / 2;
     const long long strips = (long long)pv.B * ((ld2a + 255) / 256);
     // measured (tools/callfused_sweep.py, B = 4096, n = 1000, V = 2): 64 rows per workgroup in 16-row groups streams at
     // 6.47 TB/s (32 rows: 6.19) -- a workgroup first fetches its lanes' G values, which more rows amortise
-    const int rows = t.rows_per_block > 0 ? t.rows_per_block
-                                          : (strips * pv.N >= 256LL * 8 * 64 ? 64 : (strips * pv.N >= 256LL * 4 * 8 ? 8 : 4));
+    int rows = t.rows_per_block > 0 ? t.rows_per_block
+                                    : (strips * pv.N >= 256LL * 8 * 64 ? 64 : (strips * pv.N >= 256LL * 4 * 8 ? 8 : 4));
+    if (pred && rows < 4) rows = 4;   // a folded prediction needs rows 0..2 inside one full row group (UR >= 4)
     const int c = rank2v_round_count(vcount);
     const bool big = rows >= 32;
     const bool u16 = big && t.group_rows != 8;
     switch (c) {
-        case 1: u16 ? launch_rank2v_c<16, 1>(pv, U, V, cnt, nt, rows, s) : big ? launch_rank2v_c<8, 1>(pv, U, V, cnt, nt, rows, s) : launch_rank2v_c<4, 1>(pv, U, V, cnt, nt, rows, s); break;
-        case 2: u16 ? launch_rank2v_c<16, 2>(pv, U, V, cnt, nt, rows, s) : big ? launch_rank2v_c<8, 2>(pv, U, V, cnt, nt, rows, s) : launch_rank2v_c<4, 2>(pv, U, V, cnt, nt, rows, s); break;
-        case 4: big ? launch_rank2v_c<8, 4>(pv, U, V, cnt, nt, rows, s) : launch_rank2v_c<4, 4>(pv, U, V, cnt, nt, rows, s); break;
-        case 6: big ? launch_rank2v_c<8, 6>(pv, U, V, cnt, nt, rows, s) : launch_rank2v_c<4, 6>(pv, U, V, cnt, nt, rows, s); break;
-        default: big ? launch_rank2v_c<8, kCallV>(pv, U, V, cnt, nt, rows, s) : launch_rank2v_c<4, kCallV>(pv, U, V, cnt, nt, rows, s); break;
+        case 1: u16 ? launch_rank2v_c<16, 1>(pv, U, V, cnt, nt, rows, s, pred) : big ? launch_rank2v_c<8, 1>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, 1>(pv, U, V, cnt, nt, rows, s, pred); break;
+        case 2: u16 ? launch_rank2v_c<16, 2>(pv, U, V, cnt, nt, rows, s, pred) : big ? launch_rank2v_c<8, 2>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, 2>(pv, U, V, cnt, nt, rows, s, pred); break;
+        case 4: big ? launch_rank2v_c<8, 4>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, 4>(pv, U, V, cnt, nt, rows, s, pred); break;
+        case 6: big ? launch_rank2v_c<8, 6>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, 6>(pv, U, V, cnt, nt, rows, s, pred); break;
+        default: big ? launch_rank2v_c<8, kCallV>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, kCallV>(pv, U, V, cnt, nt, rows, s, pred); break;
     }
 }
 

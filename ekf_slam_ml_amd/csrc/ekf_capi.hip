@@ -136,6 +136,7 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
         const int V = (int)vl.size() - 1;
         vl[0] = V;
         ekf::CallSrc cs{};
+        cs.trace = P.coop_trace;
         const bool by_value = P.init_flag && V <= ekf::kCallV;   // the first call needs the whole sensor vector (:113-128)
         if (by_value) {
             cs.mode = ekf::SRC_INLINE;
@@ -150,15 +151,24 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
             cs.sensor = P.call_in;
             cs.vlist = reinterpret_cast<const int*>(P.call_in + 2 * (size_t)n);
         }
-        EKFC(P.use());  // settles a deferred prediction()
+        // A prediction() deferred by ekf_predict is folded into the first pass of the call (the factor kernel applies it
+        // to its panels on the fly, the streaming pass to every other element): no launch of its own.  The first call
+        // (landmark initialisation from the predicted pose) and calls without a visible landmark settle it the plain way.
+        const bool fold = P.pred_pending && P.init_flag && V > 0;
+        EKFC(P.use(!fold));
         if (!P.init_flag) ekf::launch_measure_begin(P.pv, P.call_in, 1, P.stream);   // first call: every landmark (:113-128)
         P.init_flag = 1;
         for (int v0 = 0; v0 < V; v0 += ekf::kCallV) {
             cs.v0 = v0;
             cs.vcount = V - v0 < ekf::kCallV ? V - v0 : ekf::kCallV;
             cs.fresh_pose = v0 == 0;
+            cs.has_twist = fold && v0 == 0;
+            cs.dtheta = P.pred_dth;
+            cs.dx = P.pred_dx;
+            cs.pred_out = P.cf_pred;
             EKFC(P.call_fused_pass(cs));
         }
+        if (fold) P.pred_pending = false;
         return checked_launch();
     }
     if (P.coop_ok()) {
@@ -468,7 +478,7 @@ ekf_status ekf_cooperative_trace(ekf_handle h, int enable, long long* out, int* 
     const size_t cnt = (size_t)256 * ekf::kCoopTraceSlots;
     if (out && P.coop_trace) {
         EKFC(P.download(out, P.coop_trace, sizeof(long long) * cnt));
-        if (workgroups) *workgroups = P.coop_R > 0 ? (P.pv.N - 3 + P.coop_R - 1) / P.coop_R : 0;
+        if (workgroups) *workgroups = P.coop_ok() ? (P.pv.N - 3 + P.coop_R - 1) / P.coop_R : 2;
     }
     if (enable && !P.coop_trace) {
         EKFC(P.dalloc(&P.coop_trace, cnt));

@@ -370,14 +370,23 @@ struct CallSrc {
     // in the kernel-argument segment -- no staging buffer, no host-to-device copy, no copy -> kernel dependency
     int inl_lm[kCallV];
     double inl_xy[kCallV][2];
+    long long* trace;              // nullable diagnostics: shader-clock stamps of workgroup 0 (ekf_cooperative_trace)
+    // has_twist != 0 (first pass of a single filter's call): the prediction() that precedes the call (ekf_slam.cpp:55-106)
+    // is folded in -- k_call_factors applies At Sigma At^T + Q to its panels and the core on the fly and records
+    // (A10, A20) in pred_out[b][2]; k_rank2v applies it to every other element before the corrections.  Nothing else
+    // writes Sigma in between, so there is no separate prediction launch.
+    int has_twist;
+    double dtheta, dx;
+    double* pred_out;              // [B][2]
 };
 enum : int { SRC_INLINE = 3 };
 // U, V: [B][2 * kCallV][ld] factor rows (K_v(:,0), K_v(:,1) / G_v(0,:), G_v(1,:)); cnt [B]: corrections of this pass
 void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, double* V, int* cnt, double* state_out,
                          hipStream_t s);
 // vcount: corrections of the pass (the pool-wide maximum; filters with fewer have zero factor rows beyond theirs)
+// pred (nullable): [B][2] = (A10, A20) of a prediction to apply to every element first (single filter, see CallSrc)
 void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, int vcount, const Rank2Tuning& t,
-                   hipStream_t s);
+                   hipStream_t s, const double* pred = nullptr);
 
 // one step of an unknown-association log for every filter of a pool in ONE launch, any prefix size (ekf_stepfused.hip):
 // jmax <= kCallV readings per filter; U, V: [B][2 kCallV][ld] scratch for the step's factor pairs

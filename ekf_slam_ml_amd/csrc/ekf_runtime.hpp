@@ -210,6 +210,7 @@ struct Pool {
     int* cf_cnt = nullptr;         // [B]
     double* cf_state = nullptr;    // [B][ld] out-of-place state of the factor kernel
     double* call_in = nullptr;     // single filter: [2n] sensor_reading | [1 + n] ints: V, visible landmarks
+    double* cf_pred = nullptr;     // [B][2] (A10, A20) of a prediction folded into the call
     bool call_fused_ok() const { return call_fused && pend_cap == 0 && !active_set && pv.n > 0 && pv.N > ekf::small_max_dim(); }
     ekf_status ensure_callfused() {
         if (!cf_U) {
@@ -218,6 +219,7 @@ struct Pool {
             EKFC(dalloc(&cf_V, cnt));
             EKFC(dalloc(&cf_cnt, (size_t)pv.B));
             EKFC(dalloc(&cf_state, (size_t)pv.B * pv.ld));
+            EKFC(dalloc(&cf_pred, (size_t)pv.B * 2));
         }
         if (pv.B == 1 && !call_in) EKFC(dalloc(&call_in, (size_t)2 * pv.n + (size_t)(pv.n + 2 + 1) / 2));
         return EKF_OK;
@@ -229,7 +231,7 @@ struct Pool {
         std::swap(pv.state, cf_state);
         if (ev0) HIPC(hipEventRecord(ev0, stream));
         EKFC(prof_begin(0));
-        ekf::launch_rank2v(pv, cf_U, cf_V, cf_cnt, src.vcount, tuning, stream);
+        ekf::launch_rank2v(pv, cf_U, cf_V, cf_cnt, src.vcount, tuning, stream, src.has_twist ? cf_pred : nullptr);
         EKFC(prof_end());
         if (ev1) HIPC(hipEventRecord(ev1, stream));
         return EKF_OK;
@@ -389,7 +391,8 @@ struct Pool {
     bool pred_pending = false;
     double pred_dth = 0.0, pred_dx = 0.0;
     bool defer_predict_ok() const {
-        return (pv.B == 1 && small_path && pend_cap == 0 && pv.n > 0 && pv.N <= ekf::small_max_dim()) || coop_ok();
+        return (pv.B == 1 && small_path && pend_cap == 0 && pv.n > 0 && pv.N <= ekf::small_max_dim()) || coop_ok() ||
+               (pv.B == 1 && call_fused_ok());
     }
     void launch_predict_now(double dth, double dx) {
         // Rows/columns of landmarks this object never corrected are exactly zero against the pose block
@@ -484,7 +487,7 @@ struct Pool {
                         pv.touch_count, scores, meas_dev,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, sigma_alt, state_fz, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
-                        coop_in, coop_xchg, coop_flags, coop_trace, cf_U, cf_V, cf_cnt, cf_state, call_in};
+                        coop_in, coop_xchg, coop_flags, coop_trace, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (coop_err) (void)hipHostFree(coop_err);

@@ -127,3 +127,40 @@ if "trace" in sys.argv: trace(200, 6)
 if "ab1000" in sys.argv:
     c = synth.config3(steps=300)
     case(1000, c, [])
+
+
+if "cfonly" in sys.argv:   # for rocprofv3: the default (two launches per call) path alone, n = 200 and n = 1000
+    for n, cfg in ((200, synth.config2(steps=600)), (1000, synth.config3(steps=200))):
+        log = synth.make_known_log(cfg)
+        inputs = [log.expand_step(t) for t in range(cfg.steps)]
+        dt, _, _ = run(n, log, inputs, cfg.steps, "cf", 0)
+        print(f"n={n}: {dt / (cfg.steps - 50) * 1e6:.1f} us per tick", flush=True)
+
+
+def cf_trace(n=200, V=6):
+    """phase stamps (shader clock) of k_call_factors, workgroup 0: row 0 = control wave (core filter), row 1 = slices"""
+    rng = np.random.default_rng(1)
+    world = rng.uniform(-4, 4, size=(n, 2))
+    sensor = world.reshape(-1).copy()
+    vis = np.zeros(n, dtype=np.uint8)
+    vis[rng.choice(n, size=V, replace=False)] = 1
+    f = capi.EKF_SLAM(n)
+    f.prediction((0.01, 0.02)); f.measurement(sensor, np.zeros(n, dtype=np.uint8))
+    f.cooperative_trace(True)
+    for _ in range(6):
+        f.prediction((0.01, 0.02)); f.measurement(sensor, vis)
+    f.sync()
+    tr = f.cooperative_trace(True, fetch=True).astype(np.float64)
+    f.close()
+    c, s = tr[0], tr[1]
+    t0 = c[0]
+    print(f"k_call_factors n={n} V={V} (cycles from kernel start; 2400 cycles = 1 us)")
+    print(f"  setup: control {c[1] - t0:.0f}, slices {s[1] - t0:.0f}; after first barrier {c[2] - t0:.0f}")
+    for t in range(V + 1):
+        b = 3 + 5 * t
+        print(f"  step {t}: control terms {c[b] - t0:8.0f} KG {c[b + 1] - t0:8.0f} core update {c[b + 2] - t0:8.0f} | slice done {s[b + 2] - t0:8.0f} | "
+              f"at barrier control {c[b + 3] - t0:8.0f} slices {s[b + 3] - t0:8.0f} | released {c[b + 4] - t0:8.0f}")
+    print(f"  end {c[60] - t0:.0f}")
+
+
+if "cftrace" in sys.argv: cf_trace(200, 6)
