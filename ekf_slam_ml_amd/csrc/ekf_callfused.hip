@@ -45,15 +45,15 @@ __device__ __forceinline__ constexpr int core5(int k, int v) { return k < 3 ? k 
 // diagnostics: stamp slot k of row `who` (0: lane 0 of the control wave, 1: lane 0 of the first slice wave)
 #define CF_TR(who, k)                                                                                              \
     do {                                                                                                           \
-        if (src.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 64 * (who) && (k) < kCoopTraceSlots)         \
+        if (src.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 128 * (who) && (k) < kCoopTraceSlots)         \
             src.trace[(who) * kCoopTraceSlots + (k)] = clock64();                                                  \
     } while (0)
 
 template <int SLICE>
-__global__ __launch_bounds__(64 + SLICE) void k_call_factors(PoolView pv, CallSrc src, double* __restrict__ Uall,
+__global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallSrc src, double* __restrict__ Uall,
                                                                  double* __restrict__ Vall, int* __restrict__ cnt_out,
                                                                  double* __restrict__ state_out, int zero_upto) {
-    constexpr int kFactorThreads = 64 + SLICE;
+    constexpr int kFactorThreads = 128 + SLICE;   // wave 0: the core filter's terms and gains; wave 1: the core block update
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int N = pv.N, ld = pv.ld;
     const double* __restrict__ Sg = pv.sigma + (size_t)b * pv.sigma_stride;
@@ -168,9 +168,10 @@ __global__ __launch_bounds__(64 + SLICE) void k_call_factors(PoolView pv, CallSr
     };
 
     // ---- panels: slice thread s carries column i of Sigma[C, :] and row i of Sigma[:, C], i = slice base + s ----
-    const int s = tid - 64;
+    const int s = tid - 128;
     const int i = blockIdx.x * SLICE + s;
-    const bool slice = tid >= 64;
+    const bool slice = tid >= 128;
+    const bool w0 = tid < 64, w1 = tid >= 64 && tid < 128;
     const bool live = slice && i < N;
     double Rcol[kNcMax], Crow[kNcMax], st_i = 0.0;
     if (slice) {
@@ -186,6 +187,9 @@ __global__ __launch_bounds__(64 + SLICE) void k_call_factors(PoolView pv, CallSr
         for (int j = 0; j < kNcMax; j++)
             if (!live || j >= Nc) { Rcol[j] = 0.0; Crow[j] = 0.0; }
         if (!live) st_i = 0.0;
+    } else if (w1) {
+#pragma unroll
+        for (int j = 0; j < kNcMax; j++) { Rcol[j] = 0.0; Crow[j] = 0.0; }
     } else {
 #pragma unroll
         for (int j = 0; j < kNcMax; j++) { Rcol[j] = 0.0; Crow[j] = 0.0; }
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(64 + SLICE) void k_call_factors(PoolView pv, CallSr
     if (src.has_twist) {
         // ---- prediction(), :101-102, on what this workgroup holds (the structured arithmetic of k_predict) ----
         const double a10 = sh_pr[0], a20 = sh_pr[1];
-        if (!slice) {
+        if (w0) {
             // core block: rows / columns 1, 2 beyond the pose block, then the 3 x 3 block from its OLD values
             double c33[3][3];
             if (lane == 0)
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(64 + SLICE) void k_call_factors(PoolView pv, CallSr
                 sh_Cb[2][2] += pv.p.q_pose;
             }
             if (lane < 3) sh_sc[lane] = sh_sc[lane] + sh_pr[2 + lane];   // :99 (theta not wrapped)
-        } else if (live && i >= 3) {
+        } else if (slice && live && i >= 3) {
             Rcol[1] = a10 * Rcol[0] + Rcol[1];   // rows 1, 2 of column i
             Rcol[2] = a20 * Rcol[0] + Rcol[2];
             Crow[1] = Crow[0] * a10 + Crow[1];   // columns 1, 2 of row i
@@ -269,54 +273,68 @@ __global__ __launch_bounds__(64 + SLICE) void k_call_factors(PoolView pv, CallSr
     const double theta = sh_pose[0], x = sh_pose[1], y = sh_pose[2];
     CF_TR(0, 2); CF_TR(1, 2);
 
-    // ---- step t: wave 0 runs correction t of the core filter while the slices apply correction t - 1 ----
+    // ---- the core filter, pipelined over two wavefronts, and the slices ----
+    // gains(v): K_v and G_v on the core + the core STATE update (wave 0; needs terms(v) and the block after correction v-1)
+    auto core_gains = [&](int v) {
+        if (lane < Nc) {   // lane = core row / core column
+            double sht0 = 0.0, sht1 = 0.0, g0 = 0.0, g1 = 0.0;
 #pragma unroll
-    for (int t = 0; t <= kCallV; t++) {
-      if (t <= cnt) {   // uniform (no break: the loop must unroll so that the panel registers are indexed statically)
-        if (!slice) {
-            if (t < cnt) {
-                const int v = t;
-                auto s55 = [&](int k, int l) { return sh_Cb[core5(k, v)][core5(l, v)]; };
-                wave_terms(lane, sh_sc[3 + 2 * v], sh_sc[4 + 2 * v], sh_zs[v][0], sh_zs[v][1], theta, x, y, pv.p.r_meas, s55, true,
-                           &sh_tv[v][0], &sh_tv[v][10], &sh_tv[v][14]);
-                wave_sync_lds();
-                CF_TR(0, 3 + 5 * t);
-                if (lane < Nc) {   // K_v and G_v on the core, lane = core row / core column
-                    double sht0 = 0.0, sht1 = 0.0, g0 = 0.0, g1 = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        const double p = sh_Cb[lane][core5(k, v)];
-                        const double g = sh_Cb[core5(k, v)][lane];
-                        sht0 += p * sh_tv[v][k];
-                        sht1 += p * sh_tv[v][5 + k];
-                        g0 += sh_tv[v][k] * g;
-                        g1 += sh_tv[v][5 + k] * g;
-                    }
-                    sh_Kc[v][lane][0] = sht0 * sh_tv[v][10] + sht1 * sh_tv[v][12];   // :178
-                    sh_Kc[v][lane][1] = sht0 * sh_tv[v][11] + sht1 * sh_tv[v][13];
-                    sh_Gc[v][0][lane] = g0;
-                    sh_Gc[v][1][lane] = g1;
-                }
-                wave_sync_lds();
-                CF_TR(0, 4 + 5 * t);
-                // the core block's own rank-2 update (:191-192); compile-time divisor, positions beyond Nc hold zero factors
-#pragma unroll
-                for (int q = 0; q < (kNcMax * kNcMax + 63) / 64; q++) {
-                    const int e = lane + 64 * q;
-                    const int j = e / kNcMax, c = e - j * kNcMax;
-                    if (j < Nc && c < Nc)
-                        sh_Cb[j][c] = sh_Cb[j][c] - (sh_Kc[v][j][0] * sh_Gc[v][0][c] + sh_Kc[v][j][1] * sh_Gc[v][1][c]);
-                }
-                if (lane < Nc) {                             // core state (:186-187)
-                    double sv = sh_sc[lane] + (sh_Kc[v][lane][0] * sh_tv[v][14] + sh_Kc[v][lane][1] * sh_tv[v][15]);
-                    if (lane == 0) sv = normalize_angle(sv);
-                    sh_sc[lane] = sv;
-                }
-                wave_sync_lds();
-                CF_TR(0, 5 + 5 * t);
+            for (int k = 0; k < 5; k++) {
+                const double p = sh_Cb[lane][core5(k, v)];
+                const double g = sh_Cb[core5(k, v)][lane];
+                sht0 += p * sh_tv[v][k];
+                sht1 += p * sh_tv[v][5 + k];
+                g0 += sh_tv[v][k] * g;
+                g1 += sh_tv[v][5 + k] * g;
             }
-        } else if (t >= 1) {
-            const int v = t - 1;
+            const double k0 = sht0 * sh_tv[v][10] + sht1 * sh_tv[v][12];   // :178
+            const double k1 = sht0 * sh_tv[v][11] + sht1 * sh_tv[v][13];
+            sh_Kc[v][lane][0] = k0;
+            sh_Kc[v][lane][1] = k1;
+            sh_Gc[v][0][lane] = g0;
+            sh_Gc[v][1][lane] = g1;
+            double sv = sh_sc[lane] + (k0 * sh_tv[v][14] + k1 * sh_tv[v][15]);   // core state (:186-187)
+            if (lane == 0) sv = normalize_angle(sv);
+            sh_sc[lane] = sv;
+        }
+    };
+    auto terms_h = [&](int v) {
+        wave_terms_h(lane, sh_sc[3 + 2 * v], sh_sc[4 + 2 * v], sh_zs[v][0], sh_zs[v][1], theta, x, y, true, &sh_tv[v][0], &sh_tv[v][14]);
+    };
+    auto terms_s = [&](int v) {
+        auto s55 = [&](int k, int l) { return sh_Cb[core5(k, v)][core5(l, v)]; };
+        wave_sync_lds();
+        wave_terms_s(lane, &sh_tv[v][0], pv.p.r_meas, s55, &sh_tv[v][10]);
+        wave_sync_lds();
+    };
+    if (w0 && cnt > 0) {   // prologue: correction 0 up to its gains
+        terms_h(0);
+        terms_s(0);
+        core_gains(0);
+    }
+    // step t -- phase 1: wave 0 evaluates the state-only half of correction t+1 (its landmark is already up to date:
+    // the core state was advanced with the gains of t) WHILE wave 1 applies correction t to the core block and the slices
+    // apply it to their panels and emit its factors; phase 2: wave 0 finishes correction t+1 (S, S^-1 from the updated
+    // block), its gains and the core state.  Two workgroup barriers per correction.
+#pragma unroll
+    for (int t = 0; t < kCallV; t++) {
+      if (t < cnt) {   // uniform (no break: the loop must unroll so that the panel registers are indexed statically)
+        __syncthreads();
+        CF_TR(0, 3 + 5 * t); CF_TR(1, 3 + 5 * t);
+        const int v = t;
+        if (w0) {
+            if (t + 1 < cnt) terms_h(t + 1);
+            CF_TR(0, 4 + 5 * t);
+        } else if (w1) {
+            // the core block's own rank-2 update (:191-192); compile-time divisor, positions beyond Nc hold zero factors
+#pragma unroll
+            for (int q = 0; q < (kNcMax * kNcMax + 63) / 64; q++) {
+                const int e = lane + 64 * q;
+                const int j = e / kNcMax, c = e - j * kNcMax;
+                if (j < Nc && c < Nc)
+                    sh_Cb[j][c] = sh_Cb[j][c] - (sh_Kc[v][j][0] * sh_Gc[v][0][c] + sh_Kc[v][j][1] * sh_Gc[v][1][c]);
+            }
+        } else {
             double H0[5], H1[5];
 #pragma unroll
             for (int k = 0; k < 5; k++) { H0[k] = sh_tv[v][k]; H1[k] = sh_tv[v][5 + k]; }
@@ -353,11 +371,17 @@ __global__ __launch_bounds__(64 + SLICE) void k_call_factors(PoolView pv, CallSr
             }
             st_i = st_i + (k0 * sh_tv[v][14] + k1 * sh_tv[v][15]);   // :186
             if (i == 0) st_i = normalize_angle(st_i);                 // :187
-            CF_TR(1, 5 + 5 * t);
+            CF_TR(1, 4 + 5 * t);
         }
-        CF_TR(0, 6 + 5 * t); CF_TR(1, 6 + 5 * t);
-        __syncthreads();
-        CF_TR(0, 7 + 5 * t); CF_TR(1, 7 + 5 * t);
+        if (t + 1 < cnt) {   // uniform
+            __syncthreads();
+            CF_TR(0, 5 + 5 * t);
+            if (w0) {
+                terms_s(t + 1);
+                core_gains(t + 1);
+                CF_TR(0, 6 + 5 * t);
+            }
+        }
       }
     }
     CF_TR(0, 60); CF_TR(1, 60);
@@ -525,10 +549,10 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
 void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, double* V, int* cnt, double* state_out,
                          hipStream_t s) {
     if ((long long)pv.B * ((pv.ld + 255) / 256) >= 128)
-        hipLaunchKernelGGL(k_call_factors<256>, dim3((pv.ld + 255) / 256, pv.B), dim3(64 + 256), 0, s, pv, src, U, V, cnt,
+        hipLaunchKernelGGL(k_call_factors<256>, dim3((pv.ld + 255) / 256, pv.B), dim3(128 + 256), 0, s, pv, src, U, V, cnt,
                            state_out, rank2v_round_count(src.vcount));
     else
-        hipLaunchKernelGGL(k_call_factors<64>, dim3((pv.ld + 63) / 64, pv.B), dim3(64 + 64), 0, s, pv, src, U, V, cnt,
+        hipLaunchKernelGGL(k_call_factors<64>, dim3((pv.ld + 63) / 64, pv.B), dim3(128 + 64), 0, s, pv, src, U, V, cnt,
                            state_out, rank2v_round_count(src.vcount));
 }
 

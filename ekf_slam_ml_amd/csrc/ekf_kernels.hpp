@@ -271,6 +271,57 @@ __device__ __forceinline__ void wave_terms(int lane, double tx, double ty, doubl
     }
 }
 
+// The same in two halves, for a pipeline in which the half that needs only the STATE (reading, prediction, H, nu: the
+// trigonometry and the divisions) runs while another wavefront still updates the covariance block, and the half that
+// needs the covariance (S, S^-1) follows.  Same operations as wave_terms, result for result.
+__device__ __forceinline__ void wave_terms_h(int lane, double tx, double ty, double sx, double sy, double theta, double x,
+                                             double y, bool wrap_nu, double* outH, double* outNu) {
+    const double delta_x = tx - x, delta_y = ty - y;
+    const double d = delta_x * delta_x + delta_y * delta_y;
+    const bool pred = lane & 1;
+    const double px = pred ? delta_x : sx, py = pred ? delta_y : sy;
+    const double sq = sqrt(px * px + py * py);
+    const double at = atan2(py, px);
+    const double z0 = lane_bcast(sq, 0), z1 = lane_bcast(at, 0);
+    const double sd = lane_bcast(sq, 1), atd = lane_bcast(at, 1);
+    const double zh0 = sd, zh1 = normalize_angle(atd - theta);                       // :152-155
+    const int q = lane & 7;
+    const double num = (q == 0 || q == 3) ? -delta_x : (q == 1 || q == 6) ? -delta_y : (q == 2 || q == 5) ? delta_y : delta_x;
+    const double den = (q == 0 || q == 1 || q == 4 || q == 5) ? sd : d;
+    const double hq = num / den;
+    if (lane < 8) outH[q < 2 ? 1 + q : q < 4 ? 4 + q : q < 6 ? q - 1 : 2 + q] = hq;
+    if (lane == 8) outH[0] = 0.0;
+    if (lane == 9) outH[5] = -1.0;
+    if (lane == 0) {
+        outNu[0] = z0 - zh0;                                           // :182
+        outNu[1] = wrap_nu ? normalize_angle(z1 - zh1) : z1 - zh1;     // :183
+    }
+}
+
+template <class S55Fn>
+__device__ __forceinline__ void wave_terms_s(int lane, const double* H, double r_meas, S55Fn s55, double* outSi) {
+    const int ha = (lane / 5) & 1, hl = lane % 5;
+    double s5[5], H0[5], H1[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { s5[k] = s55(k, hl); H0[k] = H[k]; H1[k] = H[5 + k]; }
+    double hs = 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) hs += (ha ? H1[k] : H0[k]) * s5[k];
+    const int sa = (lane >> 1) & 1, sb = lane & 1;
+    double sv = 0.0;
+#pragma unroll
+    for (int l = 0; l < 5; l++) {
+        const double h0l = lane_bcast(hs, l), h1l = lane_bcast(hs, 5 + l);
+        sv += (sa ? h1l : h0l) * (sb ? H1[l] : H0[l]);
+    }
+    if (sa == sb) sv += r_meas;
+    const double S00 = lane_bcast(sv, 0), S01 = lane_bcast(sv, 1), S10 = lane_bcast(sv, 2), S11 = lane_bcast(sv, 3);
+    const double det = S00 * S11 - S01 * S10;
+    const int sq4 = lane & 3;
+    const double si = (sq4 == 0 ? S11 : sq4 == 1 ? -S01 : sq4 == 2 ? -S10 : S00) / det;
+    if (lane < 4) outSi[lane] = si;
+}
+
 // ---- host-side launchers (ekf_kernels.hip) ---------------------------------------------------
 struct Rank2Tuning {
     int rows_per_block;  // <= 0: automatic
