@@ -322,6 +322,38 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     // and may have holes) -- still hold their constructor values, and every correction of this call is
     // exactly confined to that leading block: K and H*Sigma are exact zeros outside it.  (Non-finite
     // states void this; they are already garbage in the reference.)
+    auto active_dim = [&](int j) {   // leading block that reading j of this call can touch (exact, see above)
+        if (!P.active_prefix) return P.pv.N;
+        int m = known_count + j + 1 < n ? known_count + j + 1 : n;
+        if (P.touched_hwm > m) m = P.touched_hwm;
+        return 3 + 2 * m;
+    };
+    if (!delayed && P.pv.B == 1 && P.call_fused_ok()) {
+        // beyond the LDS-resident path: ONE launch per reading (scores, decision, gain against the stored covariance minus
+        // the call's pending pairs) and ONE pass over Sigma per call (per 8 readings) -- ekf_assocfused.hip; bit-identical
+        EKFC(P.ensure_callfused());
+        P.alt_synced = false;
+        for (int j0 = 0; j0 < J; j0 += ekf::kCallV) {
+            const int jc = J - j0 < ekf::kCallV ? J - j0 : ekf::kCallV;
+            for (int jj = 0; jj < jc; jj++) {
+                const int j = j0 + jj;
+                EKFC(P.prof_begin(1));
+                ekf::launch_assoc_meas(P.pv, P.meas_dev + 2 * (size_t)j, P.pv.assoc, P.assoc_alt, P.assoc_out_dev + j, P.cf_state,
+                                       P.cf_U, P.cf_V, P.cf_cnt, jj, active_dim(j), jj == jc - 1 ? ekf::rank2v_round_count(jc) : 0,
+                                       P.stream);
+                EKFC(P.prof_end());
+                std::swap(P.pv.state, P.cf_state);
+                std::swap(P.pv.assoc, P.assoc_alt);
+            }
+            ekf::PoolView view = P.pv;
+            view.N = active_dim(j0 + jc - 1);
+            EKFC(P.prof_begin(0));
+            ekf::launch_rank2v(view, P.cf_U, P.cf_V, P.cf_cnt, jc, P.tuning, P.stream);
+            EKFC(P.prof_end());
+        }
+        EKFC(checked_launch());
+        return associate_finish(P, known_count, J, known, assoc_out);
+    }
     for (int j = 0; j < J; j++) {  // ekf_slam.cpp:291: sequential, state-carrying
         const double* mj = P.meas_dev + 2 * (size_t)j;
         int active_N = 0;

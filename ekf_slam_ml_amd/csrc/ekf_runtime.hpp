@@ -222,6 +222,7 @@ struct Pool {
             EKFC(dalloc(&cf_pred, (size_t)pv.B * 2));
         }
         if (pv.B == 1 && !call_in) EKFC(dalloc(&call_in, (size_t)2 * pv.n + (size_t)(pv.n + 2 + 1) / 2));
+        if (!assoc_alt) EKFC(dalloc(&assoc_alt, (size_t)pv.B));
         return EKF_OK;
     }
     // corrections [.., ..) of one call for every filter: factor panels, state, then the streaming pass
