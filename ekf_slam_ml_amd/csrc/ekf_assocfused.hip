@@ -3,12 +3,11 @@
 // STORED covariance minus the call's pending rank-2 pairs, then one k_rank2v pass (ekf_callfused.hip) at the end of the
 // call.  The round-1 form was two launches per reading (k_maha, k_associate_fused), the second streaming all of Sigma.
 //
+// k_assoc_score, one landmark per thread: the 25 entries of Sigma[c5(i), c5(i)] are the stored entries minus the pending
+//              pairs, in order, with the rank-2 kernel's own expression (the values the per-reading path would have
+//              read, bit for bit); summation order of innovation_cov = k_maha's shuffle folds.  (Scoring all M landmarks
+//              redundantly inside every workgroup of the next kernel was tried first: 19 us per reading at M = 1000.)
 // k_assoc_meas, grid = slices of 256 state indices (8 workgroups at n = 1000), 512 threads each:
-//   scores     EVERY workgroup scores all M known landmarks (one per thread, two rounds at M = 1000) -- redundantly, which
-//              costs less than a kernel boundary and removes the cross-workgroup reduction: the 25 entries of
-//              Sigma[c5(i), c5(i)] are the stored entries minus the pending pairs, in order, with the rank-2 kernel's
-//              own expression (the values the per-reading path would have read, bit for bit); summation order of
-//              innovation_cov = k_maha's shuffle folds
 //   decision   lexicographic (d, i) minimum, the gates 10.0 / 1.0, landmark initialisation (:293-330): identical in
 //              every workgroup; workgroup 0 records it
 //   gain       threads < 256: K(i, :) and G(:, i) of their state index from the same reconstruction of five rows /
@@ -24,12 +23,60 @@ namespace ekf {
 constexpr int kAssocThreads = 512;
 constexpr int kAssocSlice = 256;
 
+// Scores of one reading against the M known landmarks: ONE LANDMARK PER THREAD, 64-thread workgroups spread over the
+// chip (the per-landmark chain -- two atan2, the divisions of H, S, S^-1 -- is ~800 instructions; M = 1000 takes two
+// rounds on 8 redundant workgroups but one round on 16 workgroups of 64).  Leaves score and correction terms per landmark.
+__global__ __launch_bounds__(64) void k_assoc_score(PoolView pv, const double* __restrict__ meas_j,
+                                                    const AssocRec* __restrict__ assoc_in, double* __restrict__ scores,
+                                                    double* __restrict__ terms, const double* __restrict__ Ub,
+                                                    const double* __restrict__ Vb, int pc) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int ld = pv.ld;
+    const double* __restrict__ Sg = pv.sigma;
+    const double* __restrict__ st = pv.state;
+    const int M = assoc_in[0].known_count;
+    if (i >= M || i >= pv.n) return;
+    const double mx = meas_j[0], my = meas_j[1];
+    MeasTerms m;
+    measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, st[0], st[1], st[2], m);   // fresh pose, :219-221
+    double S55[5][5], S[2][2], Si[2][2];
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+#pragma unroll
+        for (int l = 0; l < 5; l++) S55[k][l] = Sg[(size_t)idx5(k, i) * ld + idx5(l, i)];
+    for (int v = 0; v < pc; v++) {   // ... as they stand NOW: minus the pending pairs of the call, in order
+        double kr[5][2], gc[5][2];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int c = idx5(k, i);
+            kr[k][0] = Ub[(size_t)(2 * v) * ld + c]; kr[k][1] = Ub[(size_t)(2 * v + 1) * ld + c];
+            gc[k][0] = Vb[(size_t)(2 * v) * ld + c]; gc[k][1] = Vb[(size_t)(2 * v + 1) * ld + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
+    }
+    innovation_cov(S55, m.H, pv.p.r_meas, S);   // sums in the order of k_maha's shuffle folds
+    inv2(S, Si);
+    const double v0 = m.z0 - m.zh0, v1 = m.z1 - m.zh1;   // bearing NOT wrapped, :269
+    const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
+    const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
+    scores[i] = t0 * v0 + t1 * v1;
+    double* tr = terms + (size_t)i * 16;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { tr[k] = m.H[0][k]; tr[5 + k] = m.H[1][k]; }
+    tr[10] = Si[0][0]; tr[11] = Si[0][1]; tr[12] = Si[1][0]; tr[13] = Si[1][1];
+    tr[14] = v0; tr[15] = v1;
+}
+
 __global__ __launch_bounds__(kAssocThreads) void k_assoc_meas(PoolView pv, const double* __restrict__ meas_j,
                                                               const AssocRec* __restrict__ assoc_in,
                                                               AssocRec* __restrict__ assoc_next, int* __restrict__ assoc_out_j,
                                                               double* __restrict__ state_out, double* __restrict__ Uall,
                                                               double* __restrict__ Vall, int* __restrict__ cnt_out, int pc,
-                                                              int Nb, int zero_upto) {
+                                                              int Nb, int zero_upto, const double* __restrict__ scores,
+                                                              const double* __restrict__ terms) {
     const int tid = threadIdx.x;
     const int n = pv.n, ld = pv.ld;
     const double* __restrict__ Sg = pv.sigma;
@@ -65,46 +112,12 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_meas(PoolView pv, const
     }
     __syncthreads();
 
-    // ---- scores, :300-309 ----
+    // ---- scores, :300-309: left by k_assoc_score ----
     double best = pv.p.gate_new;  // :293
     int bi = INT_MAX;
-    double bH[10], bSi[4], bnu[2];
     for (int i = tid; i < M; i += kAssocThreads) {
-        MeasTerms m;
-        measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, theta, x, y, m);
-        double S55[5][5], S[2][2], Si[2][2];
-        const int ia = 3 + 2 * i;
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-#pragma unroll
-            for (int l = 0; l < 5; l++) S55[k][l] = Sg[(size_t)idx5(k, i) * ld + idx5(l, i)];
-        for (int v = 0; v < pc; v++) {   // ... as they stand NOW: minus the pending pairs of the call, in order
-            double kr[5][2], gc[5][2];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { kr[k][0] = sh_K5[v][k][0]; kr[k][1] = sh_K5[v][k][1]; gc[k][0] = sh_G5[v][k][0]; gc[k][1] = sh_G5[v][k][1]; }
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                kr[3 + q][0] = Ub[(size_t)(2 * v) * ld + ia + q]; kr[3 + q][1] = Ub[(size_t)(2 * v + 1) * ld + ia + q];
-                gc[3 + q][0] = Vb[(size_t)(2 * v) * ld + ia + q]; gc[3 + q][1] = Vb[(size_t)(2 * v + 1) * ld + ia + q];
-            }
-#pragma unroll
-            for (int k = 0; k < 5; k++)
-#pragma unroll
-                for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
-        }
-        innovation_cov(S55, m.H, pv.p.r_meas, S);
-        inv2(S, Si);
-        const double v0 = m.z0 - m.zh0, v1 = m.z1 - m.zh1;   // bearing NOT wrapped, :269
-        const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
-        const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
-        const double sc = t0 * v0 + t1 * v1;
-        if (sc < best) {   // :305-309 (NaN never wins)
-            best = sc; bi = i;
-#pragma unroll
-            for (int k = 0; k < 5; k++) { bH[k] = m.H[0][k]; bH[5 + k] = m.H[1][k]; }
-            bSi[0] = Si[0][0]; bSi[1] = Si[0][1]; bSi[2] = Si[1][0]; bSi[3] = Si[1][1];
-            bnu[0] = v0; bnu[1] = v1;
-        }
+        const double d = scores[i];
+        if (d < best) { best = d; bi = i; }  // :305-309 (NaN never wins)
     }
     double rd = best;
     int ri = bi;
@@ -165,13 +178,12 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_meas(PoolView pv, const
         sh_K5[v][3 + q][h] = Ub[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
         sh_G5[v][3 + q][h] = Vb[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
     }
-    if (!is_new && bi == lm) {
-#pragma unroll
-        for (int k = 0; k < 10; k++) sh_H[k] = bH[k];
-#pragma unroll
-        for (int k = 0; k < 4; k++) sh_Si[k] = bSi[k];
-        sh_nu[0] = bnu[0];
-        sh_nu[1] = normalize_angle(bnu[1]);   // :183 (the score used it unwrapped)
+    if (!is_new && tid < 16) {   // the winner's terms as the scoring kernel left them
+        const double tv = terms[(size_t)lm * 16 + tid];
+        if (tid < 10) sh_H[tid] = tv;
+        else if (tid < 14) sh_Si[tid - 10] = tv;
+        else if (tid == 14) sh_nu[0] = tv;
+        else sh_nu[1] = normalize_angle(tv);   // :183 (the score used it unwrapped)
     }
     __syncthreads();
     if (is_new && tid == 0) {   // :331-381 with the fresh pose: a new landmark has no score record
@@ -234,9 +246,12 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_meas(PoolView pv, const
 }
 
 void launch_assoc_meas(const PoolView& pv, const double* meas_j, const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j,
-                       double* state_out, double* U, double* V, int* cnt_out, int pc, int Nb, int zero_upto, hipStream_t s) {
+                       double* state_out, double* U, double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound,
+                       double* scores, double* terms, hipStream_t s) {
+    if (m_bound > 0)
+        hipLaunchKernelGGL(k_assoc_score, dim3((m_bound + 63) / 64), dim3(64), 0, s, pv, meas_j, assoc_in, scores, terms, U, V, pc);
     hipLaunchKernelGGL(k_assoc_meas, dim3((pv.ld + kAssocSlice - 1) / kAssocSlice), dim3(kAssocThreads), 0, s, pv, meas_j, assoc_in,
-                       assoc_next, assoc_out_j, state_out, U, V, cnt_out, pc, Nb, zero_upto);
+                       assoc_next, assoc_out_j, state_out, U, V, cnt_out, pc, Nb, zero_upto, scores, terms);
 }
 
 }  // namespace ekf

@@ -328,10 +328,14 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         if (P.touched_hwm > m) m = P.touched_hwm;
         return 3 + 2 * m;
     };
-    if (!delayed && P.pv.B == 1 && P.call_fused_ok()) {
-        // beyond the LDS-resident path: ONE launch per reading (scores, decision, gain against the stored covariance minus
-        // the call's pending pairs) and ONE pass over Sigma per call (per 8 readings) -- ekf_assocfused.hip; bit-identical
+    // Big discovered prefixes (>= 1400: from ~15 MB of covariance per reading): scores / decision + gain against the stored
+    // covariance minus the call's pending pairs (two small launches per reading) and ONE pass over Sigma per call (per 8
+    // readings) -- ekf_assocfused.hip; bit-identical.  Measured at n = 1000, known = 1000 (tools/assoc_bench.py):
+    // 24.5 us per reading against 26.6 us for scores + one streaming launch per reading; below that size the streaming
+    // launch is cheap and two launches per reading win (configs[2]'s discovery run: 12.7 k vs 10.5 k steps/s).
+    if (!delayed && P.pv.B == 1 && P.call_fused_ok() && active_dim(0) >= 1400) {
         EKFC(P.ensure_callfused());
+        if (!P.terms) EKFC(P.dalloc(&P.terms, (size_t)(n > 0 ? n : 1) * 16));
         P.alt_synced = false;
         for (int j0 = 0; j0 < J; j0 += ekf::kCallV) {
             const int jc = J - j0 < ekf::kCallV ? J - j0 : ekf::kCallV;
@@ -340,7 +344,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
                 EKFC(P.prof_begin(1));
                 ekf::launch_assoc_meas(P.pv, P.meas_dev + 2 * (size_t)j, P.pv.assoc, P.assoc_alt, P.assoc_out_dev + j, P.cf_state,
                                        P.cf_U, P.cf_V, P.cf_cnt, jj, active_dim(j), jj == jc - 1 ? ekf::rank2v_round_count(jc) : 0,
-                                       P.stream);
+                                       known_count + j < n ? known_count + j : n, P.scores, P.terms, P.stream);
                 EKFC(P.prof_end());
                 std::swap(P.pv.state, P.cf_state);
                 std::swap(P.pv.assoc, P.assoc_alt);

@@ -443,7 +443,8 @@ void launch_rank2v(const PoolView& pv, const double* U, const double* V, const i
 // (scores against the stored covariance minus the call's pc pending pairs, decision, gain -> pair pc, state out of
 // place); the caller ends the call with launch_rank2v.  Nb: active dimension of the reading (discovered prefix).
 void launch_assoc_meas(const PoolView& pv, const double* meas_j, const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j,
-                       double* state_out, double* U, double* V, int* cnt_out, int pc, int Nb, int zero_upto, hipStream_t s);
+                       double* state_out, double* U, double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound,
+                       double* scores, double* terms, hipStream_t s);
 int rank2v_round_count(int vcount);   // corrections per pass, rounded up to an instantiated count of k_rank2v
 
 // one step of an unknown-association log for every filter of a pool in ONE launch, any prefix size (ekf_stepfused.hip):
