@@ -285,6 +285,146 @@ __global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Flush, second form (pools that fill the chip): a workgroup of 16 waves owns a strip of 256 columns for a row range.
+//   * The strip of all pending V rows (count x 2 KB, <= 128 KB) is read ONCE into LDS and shared by the waves: V
+//     costs no L2 bandwidth and no vector-memory wait in the FMA loop (k_flush: two L2 loads per pair and wave,
+//     waited for in the trip that issues them -- hipcc collapses the source's rotating prefetch).
+//   * A lane holds 8 rows x 4 columns (k_flush: 16 x 2): the same 64 accumulator registers, but a scalar operand
+//     U[j](r) now feeds FOUR v_fma_f64, so one batch of scalar loads (64 SGPRs: 4 vectors x 8 rows) is followed by
+//     128 FMAs instead of 64.  Scalar loads return out of order: only one batch can be in flight, its latency
+//     (~1600 cycles under a saturated L2, from the measured 50% FMA utilisation of the 2-vector form) is exposed
+//     once per batch and covered by the other three waves of the SIMD only -- halving the batches per unit of work
+//     is what lifts the FMA pipe from ~50% busy towards the HBM time of the stream.
+// Same order of fused multiply-adds per element as k_flush -> bit-identical results.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStripWaves = 16;
+constexpr int kStripCols2 = 128;   // double2 columns per strip: lane l holds columns l and l + 64
+
+// `col` = the lane's first column (base + c); its second column is 64 double2 (1 KB) further on: one address register
+// pair per row serves both.  live0 / live1: lanes past the last column of the matrix take no part.
+// `last`: the last row of the workgroup's range -- the rows of a partial group behind it re-read that row (never stored).
+template <bool NT>
+__device__ __forceinline__ void fl_load(double2_t (&a)[8][2], const double2_t* __restrict__ col, int r, int last, int ld2n,
+                                        bool live0, bool live1) {
+    if (live0) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const size_t row = min(r + u, last);
+            if constexpr (NT) a[u][0] = __builtin_nontemporal_load(col + row * ld2n);
+            else a[u][0] = col[row * ld2n];
+        }
+    }
+    if (live1) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const size_t row = min(r + u, last);
+            if constexpr (NT) a[u][1] = __builtin_nontemporal_load(col + row * ld2n + 64);
+            else a[u][1] = col[row * ld2n + 64];
+        }
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void fl_store(const double2_t (&a)[8][2], double2_t* __restrict__ col, int r, int last, int ld2n,
+                                         bool live0, bool live1) {
+    if (live0) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (r + u > last) break;   // wave-uniform
+            if constexpr (NT) __builtin_nontemporal_store(a[u][0], col + (size_t)(r + u) * ld2n);
+            else col[(size_t)(r + u) * ld2n] = a[u][0];
+        }
+    }
+    if (live1) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (r + u > last) break;
+            if constexpr (NT) __builtin_nontemporal_store(a[u][1], col + (size_t)(r + u) * ld2n + 64);
+            else col[(size_t)(r + u) * ld2n + 64] = a[u][1];
+        }
+    }
+}
+// a(u, .) -= sum over VEC vectors of U[j](r+u) V[j](c): one batch of scalar loads, 2 VEC ds_read_b128, 32 VEC FMAs
+template <int VEC>
+__device__ __forceinline__ void fl_batch(double2_t (&a)[8][2], const double* __restrict__ Ur, int ld,
+                                         const double2_t* __restrict__ shv) {
+    double k[VEC][8];
+    double2_t v[VEC][2];
+#pragma unroll
+    for (int q = 0; q < VEC; q++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) k[q][u] = Ur[(size_t)q * ld + u];   // wave-uniform address -> s_load_dwordx16
+        v[q][0] = shv[q * kStripCols2];
+        v[q][1] = shv[q * kStripCols2 + 64];
+    }
+    // A scheduling barrier keeps the batch's s_load_dwordx16 together in front of the FMAs.  (Left alone, hipcc moves
+    // each scalar load down to its use to shorten the SGPR live ranges, and the scalar-load latency is exposed once
+    // per vector instead of once per batch.)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < VEC; q++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            a[u][0].x = __builtin_fma(-k[q][u], v[q][0].x, a[u][0].x);
+            a[u][0].y = __builtin_fma(-k[q][u], v[q][0].y, a[u][0].y);
+            a[u][1].x = __builtin_fma(-k[q][u], v[q][1].x, a[u][1].x);
+            a[u][1].y = __builtin_fma(-k[q][u], v[q][1].y, a[u][1].y);
+        }
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __restrict__ sigma,
+                                                                     const double* __restrict__ Uall,
+                                                                     const double* __restrict__ Vall, int N, int ld,
+                                                                     size_t sigma_stride, int cap, int count,
+                                                                     int rows_per_block, int strips, int row_blocks, int B) {
+    extern __shared__ double2_t sh_V[];   // [count][kStripCols2]
+    const int P = strips * row_blocks;
+    int b, p;
+    const int full = (B / 8) * 8 * P;     // (a filter's workgroups share one XCD's L2: see k_flush)
+    if ((int)blockIdx.x < full) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b = (slot / P) * 8 + xcd;
+        p = slot % P;
+    } else {
+        const int rest = blockIdx.x - full;
+        b = (B / 8) * 8 + rest / P;
+        p = rest % P;
+    }
+    const int ld2n = ld >> 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cbase = (p % strips) * kStripCols2 + lane;
+    const bool live0 = cbase < ld2n, live1 = cbase + 64 < ld2n;
+    const int row_begin = (p / strips) * rows_per_block;
+    const int row_end = min(N, row_begin + rows_per_block);
+    const double* __restrict__ Ub = Uall + (size_t)b * cap * ld;
+    const double2_t* __restrict__ Vb = reinterpret_cast<const double2_t*>(Vall + (size_t)b * cap * ld);
+    double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + cbase;
+
+    const double2_t zero2 = {0.0, 0.0};
+    for (int j = wave; j < count; j += kStripWaves) {
+        sh_V[j * kStripCols2 + lane] = live0 ? Vb[(size_t)j * ld2n + cbase] : zero2;
+        sh_V[j * kStripCols2 + 64 + lane] = live1 ? Vb[(size_t)j * ld2n + cbase + 64] : zero2;
+    }
+    __syncthreads();
+    const double2_t* __restrict__ shv = sh_V + lane;
+
+    // 8-row groups, the last one possibly partial: its missing rows re-read the last row and are never stored (their
+    // scalar operands come from the padding of the U rows: r + 7 < ld).  Wave w takes the groups w, w + 16, ...
+    const int ngroups = (row_end - row_begin + 7) >> 3;
+    for (int g = wave; g < ngroups; g += kStripWaves) {
+        const int r = row_begin + 8 * g;
+        double2_t a[8][2];
+        fl_load<NT>(a, col, r, row_end - 1, ld2n, live0, live1);
+        int j = 0;
+        for (; j + 4 <= count; j += 4) fl_batch<4>(a, Ub + (size_t)j * ld + r, ld, shv + j * kStripCols2);
+        if (j < count) fl_batch<2>(a, Ub + (size_t)j * ld + r, ld, shv + j * kStripCols2);   // (count is even)
+        fl_store<NT>(a, col, r, row_end - 1, ld2n, live0, live1);
+    }
+}
+
 void launch_gain_delayed(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
                          hipStream_t s) {
     hipLaunchKernelGGL(k_gain_delayed, dim3((pv.ld / 2 + 255) / 256, pv.B), dim3(256), 0, s, pv, src, pend, state_out);
@@ -294,6 +434,32 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
     if (pend.count <= 0) return;
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
+    // strip form: the V strip in LDS (count x 2 KB, one workgroup of 16 waves per CU) and >= 2 workgroups per CU of work
+    const bool forced = t.rows_per_block == -2;   // (tests: the strip form on pools of any size)
+    if ((forced || (t.rows_per_block == 0 && pv.N >= 256)) && pend.count <= 64) {
+        const int strips = (pv.ld / 2 + kStripCols2 - 1) / kStripCols2;
+        int row_blocks = 1;
+        while ((long long)pv.B * strips * row_blocks < 1024 && pv.N / (row_blocks * 2) >= 512) row_blocks *= 2;
+        static int attr_ok = -1;   // dynamic LDS beyond 64 KB has to be allowed per kernel (once)
+        if (attr_ok < 0)
+            attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kStripCols2 * 16) == hipSuccess &&
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kStripCols2 * 16) == hipSuccess;
+        if (attr_ok && (forced || (long long)pv.B * strips * row_blocks >= 512)) {
+            const int rows = (((pv.N + row_blocks - 1) / row_blocks) + 7) & ~7;
+            row_blocks = (pv.N + rows - 1) / rows;
+            dim3 grid((unsigned)((long long)strips * row_blocks * pv.B));
+            const size_t lds = (size_t)pend.count * kStripCols2 * sizeof(double2_t);
+            if (nt) hipLaunchKernelGGL((k_flush_strip<true>), grid, dim3(64 * kStripWaves), lds, s, pv.sigma, pend.U,
+                                       pend.V, pv.N, pv.ld, pv.sigma_stride, pend.cap, pend.count, rows, strips,
+                                       row_blocks, pv.B);
+            else hipLaunchKernelGGL((k_flush_strip<false>), grid, dim3(64 * kStripWaves), lds, s, pv.sigma, pend.U,
+                                    pend.V, pv.N, pv.ld, pv.sigma_stride, pend.cap, pend.count, rows, strips,
+                                    row_blocks, pv.B);
+            return;
+        }
+    }
     int rows = t.rows_per_block > 0 ? t.rows_per_block : 16;  // measured: tools/flush_sweep.py
     const long long all_strips = (long long)pv.B * ((pv.ld / 2 + 255) / 256);
     if (t.rows_per_block <= 0 && all_strips * pv.N < 256LL * 8 * 32) rows = 8;

@@ -171,3 +171,30 @@ def test_delayed_data_association_without_flush(hip, oracle, k):
     assert total > 60 and ko.sum() >= 6
     assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, f"delayed association k={k}")
     f.close()
+
+
+@pytest.mark.parametrize("B,n,k,vmax", [(3, 130, 5, 3), (9, 500, 16, 2), (4, 1000, 8, 4), (2, 333, 3, 1), (5, 61, 32, 1)])
+def test_strip_form_flush_is_bit_identical_to_the_plain_flush(hip, B, n, k, vmax):
+    """k_flush_strip (pools that fill the chip: V strip in LDS, 8 rows x 4 columns per lane, 4-vector scalar batches)
+    applies the pending pairs to every element in the same order with the same fused multiply-adds as k_flush: forced
+    here on small pools (set_tuning(rows_per_block=-2)) and compared bit for bit -- strips that end inside the matrix
+    (ld/2 not a multiple of 128), N not a multiple of 8 (partial last group), pending counts that are not a
+    multiple of 4 (k odd with one correction per step) and ragged counts across filters (zero pairs)."""
+    cfg = synth.SimConfig(n=n, steps=2 * k + 3, filters=B, seed=4000 + n, half_extent=4.0, min_spacing=0.15,
+                          max_visible_dis=1e9 if vmax == 1 else 2.0, vmax=vmax)
+    log = synth.make_known_log(cfg)
+    res = []
+    for rows in (-2, -1, 16):
+        bt = hip.BatchEKF(B, n)
+        bt.set_update_mode(k)
+        bt.set_tuning(rows_per_block=rows)
+        bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+        st = bt.run_known(0, cfg.steps, time_kernels=True)
+        assert st["rank2_launches"] >= 2
+        res.append(([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)]))
+        bt.close()
+    for other in (1, 2):
+        for b in range(B):
+            assert np.array_equal(res[0][0][b], res[other][0][b]), f"filter {b} state"
+            assert np.array_equal(res[0][1][b], res[other][1][b]), f"filter {b} covariance"
+    assert np.all(np.isfinite(res[0][1][0]))
