@@ -421,6 +421,11 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
         int j = 0;
         for (; j + 4 <= count; j += 4) fl_batch<4>(a, Ub + (size_t)j * ld + r, ld, shv + j * kStripCols2);
         if (j < count) fl_batch<2>(a, Ub + (size_t)j * ld + r, ld, shv + j * kStripCols2);   // (count is even)
+        // An explicit vmcnt(0): nothing is outstanding here but the previous group's stores, a whole FMA phase old.
+        // Without it hipcc keeps treating the group's loads as possibly pending (the zero-trip path of the loop above)
+        // and puts an `s_waitcnt vmcnt(7)` in front of every store: at most 8 stores of a wave in flight, a stall for
+        // a write acknowledgement before the next group's loads can be issued.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         fl_store<NT>(a, col, r, row_end - 1, ld2n, live0, live1);
     }
 }
@@ -434,9 +439,12 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
     if (pend.count <= 0) return;
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
-    // strip form: the V strip in LDS (count x 2 KB, one workgroup of 16 waves per CU) and >= 2 workgroups per CU of work
-    const bool forced = t.rows_per_block == -2;   // (tests: the strip form on pools of any size)
-    if ((forced || (t.rows_per_block == 0 && pv.N >= 256)) && pend.count <= 64) {
+    // Strip form: the V strip in LDS (count x 2 KB, one workgroup of 16 waves per CU) and >= 2 workgroups per CU of
+    // work.  Its time does not depend on the count (47.5 ms at B = 4096, n = 1000: bound by its access pattern at
+    // 5.5 TB/s), the plain form's does (41.5 ms up to 32 vectors = the stream floor, 58.9 ms at 64:
+    // tools/flush_sweep.py) -- the strip form takes over beyond 40 pending vectors.
+    const bool forced = t.rows_per_block == -2;   // (tests: the strip form on pools of any size, any count <= 64)
+    if ((forced || (t.rows_per_block == 0 && pv.N >= 256 && pend.count > 40)) && pend.count <= 64) {
         const int strips = (pv.ld / 2 + kStripCols2 - 1) / kStripCols2;
         int row_blocks = 1;
         while ((long long)pv.B * strips * row_blocks < 1024 && pv.N / (row_blocks * 2) >= 512) row_blocks *= 2;
