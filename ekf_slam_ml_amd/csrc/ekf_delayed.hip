@@ -403,21 +403,38 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
     const double2_t* __restrict__ Vb = reinterpret_cast<const double2_t*>(Vall + (size_t)b * cap * ld);
     double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + cbase;
 
+    // 8-row groups, the last one possibly partial: its missing rows re-read the last row and are never stored (their
+    // scalar operands come from the padding of the U rows: r + 7 < ld).  Wave w takes the groups w, w + 16, ...
+    const int ngroups = (row_end - row_begin + 7) >> 3;
+    int g = wave;
+    double2_t a[8][2];
+    // the first group's loads go out BEFORE the V strip is staged: the two latencies overlap (a workgroup that owns a
+    // few hundred rows only would otherwise spend ~10 % of its life in front of the barrier)
+    if (g < ngroups) fl_load<NT>(a, col, row_begin + 8 * g, row_end - 1, ld2n, live0, live1);
+
     const double2_t zero2 = {0.0, 0.0};
-    for (int j = wave; j < count; j += kStripWaves) {
-        sh_V[j * kStripCols2 + lane] = live0 ? Vb[(size_t)j * ld2n + cbase] : zero2;
-        sh_V[j * kStripCols2 + 64 + lane] = live1 ? Vb[(size_t)j * ld2n + cbase + 64] : zero2;
+    {   // V strip -> LDS: wave w stages the vectors w, w + 16, w + 32, w + 48, all their loads in flight together
+        double2_t v[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = min(wave + kStripWaves * q, count - 1);
+            v[q][0] = live0 ? Vb[(size_t)j * ld2n + cbase] : zero2;
+            v[q][1] = live1 ? Vb[(size_t)j * ld2n + cbase + 64] : zero2;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = wave + kStripWaves * q;
+            if (j < count) {
+                sh_V[j * kStripCols2 + lane] = v[q][0];
+                sh_V[j * kStripCols2 + 64 + lane] = v[q][1];
+            }
+        }
     }
     __syncthreads();
     const double2_t* __restrict__ shv = sh_V + lane;
 
-    // 8-row groups, the last one possibly partial: its missing rows re-read the last row and are never stored (their
-    // scalar operands come from the padding of the U rows: r + 7 < ld).  Wave w takes the groups w, w + 16, ...
-    const int ngroups = (row_end - row_begin + 7) >> 3;
-    for (int g = wave; g < ngroups; g += kStripWaves) {
+    while (g < ngroups) {
         const int r = row_begin + 8 * g;
-        double2_t a[8][2];
-        fl_load<NT>(a, col, r, row_end - 1, ld2n, live0, live1);
         int j = 0;
         for (; j + 4 <= count; j += 4) fl_batch<4>(a, Ub + (size_t)j * ld + r, ld, shv + j * kStripCols2);
         if (j < count) fl_batch<2>(a, Ub + (size_t)j * ld + r, ld, shv + j * kStripCols2);   // (count is even)
@@ -427,6 +444,8 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
         // a write acknowledgement before the next group's loads can be issued.
         __builtin_amdgcn_s_waitcnt(0x0F70);
         fl_store<NT>(a, col, r, row_end - 1, ld2n, live0, live1);
+        g += kStripWaves;
+        if (g < ngroups) fl_load<NT>(a, col, row_begin + 8 * g, row_end - 1, ld2n, live0, live1);
     }
 }
 
@@ -440,9 +459,10 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
     // Strip form: the V strip in LDS (count x 2 KB, one workgroup of 16 waves per CU) and >= 2 workgroups per CU of
-    // work.  Its time does not depend on the count (47.5 ms at B = 4096, n = 1000: bound by its access pattern at
-    // 5.5 TB/s), the plain form's does (41.5 ms up to 32 vectors = the stream floor, 58.9 ms at 64:
-    // tools/flush_sweep.py) -- the strip form takes over beyond 40 pending vectors.
+    // work.  Its time hardly depends on the count (45-47 ms at B = 4096, n = 1000: 5.5 TB/s -- workgroups that sweep a
+    // whole column strip stream ~10 % below workgroups dispatched in address order, and shorter row ranges pay the V
+    // staging once per range: 48.5 ms at 1024 rows, 52 at 512, 58 at 256), the plain form's does (41.5 ms up to 32
+    // vectors = the stream floor, 58.9 ms at 64: tools/flush_sweep.py) -- the strip form takes over beyond 40.
     const bool forced = t.rows_per_block == -2;   // (tests: the strip form on pools of any size, any count <= 64)
     if ((forced || (t.rows_per_block == 0 && pv.N >= 256 && pend.count > 40)) && pend.count <= 64) {
         const int strips = (pv.ld / 2 + kStripCols2 - 1) / kStripCols2;

@@ -1,20 +1,23 @@
 """Flush time of the delayed update at BASELINE.json configs[4]'s shape: strip form (k_flush_strip; automatic beyond 40
 pending vectors on pools that fill the chip) against the plain form (k_flush), non-temporal access on / off, k =
 corrections per flush (two pending vectors each).
-usage: python tools/flush_sweep.py [B=4096]"""
+usage: python tools/flush_sweep.py [B=4096] [k,k,...] [nt,nt]   (rocprofv3 --pmc FETCH_SIZE -- python3 tools/flush_sweep.py 4096 32 1
+collects the HBM read traffic of both forms)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ekf_slam_ml_amd import capi, synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+KS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [4, 8, 16, 32]
+NTS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 0]
 K, W = 32, 2
 cfg = synth.config5(filters=B, steps=1 + W + K, n=1000)
 bt = capi.BatchEKF(B, 1000)
 bt.simulate_known_log(cfg, synth.make_world(1000, cfg.half_extent, cfg.min_spacing, cfg.world_seed))
-for k in (4, 8, 16, 32):
+for k in KS:
     for rows, name in ((-2, "strip"), (-1, "plain"), (0, "automatic")):   # (2k pending vectors per flush)
-        for nt in (1, 0):
+        for nt in NTS:
             bt.reset(); bt.set_update_mode(k, 0); bt.set_tuning(rows, nt, 0)
             bt.run_known(0, 1 + W)
             st = bt.run_known(1 + W, 1 + W + K, time_kernels=True)
