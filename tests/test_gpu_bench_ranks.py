@@ -1,0 +1,48 @@
+"""-m gpu: bench.py's multi-rank path on the real HIP library.  One MI355X per test box, and RCCL refuses two ranks
+on one device, so the ranks rendezvous over gloo (EKF_DIST_BACKEND=gloo, bench.py's rehearsal mode) and share the GPU;
+everything else is the path the driver launches for --gpus N: torch.distributed.run, one process per rank, global
+filter ids from shard.shard(), barrier + synchronize around the timed region, MAX over ranks of the wall time, SUM of
+the work, one JSON line from rank 0.  (The sharding arithmetic itself is covered on the CPU by tests/test_distributed.py.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--steps", "3", "--warmup", "1", "--filters", "96", "--landmarks", "300", "--only-main", "--no-cpu-baseline"]
+
+
+def _line(out):
+    rows = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(rows) == 1, out[-2000:]          # ONE JSON line, printed by rank 0 only
+    return json.loads(rows[0])
+
+
+def test_two_ranks_through_torchrun_aggregate_like_one():
+    env = dict(os.environ, EKF_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + ARGS, capture_output=True,
+                         text=True, timeout=600, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2"] + ARGS, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = _line(one.stdout), _line(two.stdout)
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["scaling"] == "weak"
+    assert b["config"]["ranks_seen"] == 2 and b["config"]["filters_per_gpu"] == a["config"]["filters_per_gpu"] == 96
+    # weak scaling: every rank does the single-rank job's work -> twice the corrections in the aggregate
+    work_a = a["value"] * a["ms_per_step"] * a["steps"]
+    work_b = b["value"] * b["ms_per_step"] * b["steps"]
+    assert abs(work_b / work_a - 2.0) < 1e-9
+    assert b["metric"] == a["metric"] and b["unit"] == a["unit"] and b["steps"] == 3 and b["warmup"] == 1
+
+
+def test_launcher_rank_count_mismatch_is_refused():
+    env = dict(os.environ, EKF_DIST_BACKEND="gloo", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"] + ARGS, capture_output=True,
+                       text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "--gpus 4 but the launcher started 2" in (r.stderr + r.stdout)
