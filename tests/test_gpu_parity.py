@@ -547,3 +547,40 @@ def test_row_packed_rank2_is_bit_identical(hip, n, B):
     for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
         assert np.array_equal(a, b)
     assert np.allclose(res[0][2], res[1][2], rtol=1e-12)
+
+
+def test_maximum_map_size_n5000(hip, oracle):
+    """The largest map of BASELINE.json's configs (n = 5000, N = 10003, Sigma = 800 MB in fp64) through the fp64 filter
+    itself (configs[3] times only the fp32 dense propagation at this size): known association once per call and once
+    per landmark (bit-identical to each other), then data_association() against the whole map, all against the
+    structured CPU checker."""
+    n = 5000
+    cfg = synth.SimConfig(n=n, steps=4, half_extent=30.0, min_spacing=0.2, max_visible_dis=2.5, vmax=5, seed=5000)
+    log = synth.make_known_log(cfg)
+    assert (log.lm_idx[:, 0] >= 0).sum() >= 8
+    res = []
+    for call_fused in (True, False):
+        f = hip.EKF_SLAM(n)
+        f.set_call_fused(call_fused)
+        for t in range(cfg.steps):
+            sensor, vis = log.expand_step(t)
+            f.prediction(log.twist[t, 0]); f.measurement(sensor, vis)
+        res.append((f.state, f.cov[::97].copy()))      # (every 97th row: 83 MB instead of 800)
+        if call_fused:
+            f.close()
+            continue
+        o = oracle.OracleEKF(n, oracle.STRUCTURED)
+        for t in range(cfg.steps):
+            sensor, vis = log.expand_step(t)
+            o.prediction(*log.twist[t, 0]); o.measurement(sensor, vis)
+        # two readings against the whole map (all 5000 landmarks known): a re-observation and one far from everything
+        known_f, known_o = np.ones(n, dtype=np.uint8), np.ones(n, dtype=np.uint8)
+        last = log.lm_idx[cfg.steps - 1, 0]
+        i = int(last[last >= 0][0])
+        m = np.array([sensor[2 * i:2 * i + 2], [55.0, -41.0]])
+        f.prediction((0.01, 0.02)); o.prediction(0.01, 0.02)
+        a, b = f.data_association(m, known_f), o.data_association(m, known_o)
+        assert np.array_equal(a, b) and a[0] >= 0 and a[1] == -1
+        assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "n = 5000")
+        f.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
