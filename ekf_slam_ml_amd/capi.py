@@ -554,8 +554,9 @@ class BatchEKF:
         _check(self._lib.ekf_batch_set_call_fused(self._h, int(bool(enable))))
 
     def set_step_fused(self, enable=True):
-        """unknown association beyond the LDS-resident path: one launch per step (default) / four per measurement slot"""
-        _check(self._lib.ekf_batch_set_step_fused(self._h, int(bool(enable))))
+        """unknown association beyond the LDS-resident path: True / 1 = one launch per step, two for big prefixes
+        (default); 2 = always one launch; False / 0 = four launches per measurement slot"""
+        _check(self._lib.ekf_batch_set_step_fused(self._h, int(enable)))
 
     def rank2_kernel(self):
         """name of the k_rank2 instantiation a full-width eager correction of this pool launches, + rows per workgroup"""

@@ -406,7 +406,12 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
 // (At Sigma At^T + Q)(r, c) -- rows 1, 2 take a_r * row 0, columns 1, 2 take column 0 * a_c, the 3 x 3 pose block its own
 // formula (the structured arithmetic of k_predict, operation for operation) -- all from values this lane or its wave
 // neighbours hold: row 0 sits in the same row group as rows 1, 2, column 0 in lane 0 of strip 0.
-template <int UR, bool NT, int CNT, bool PRED>
+// KL: the K values of the workgroup's row block (<= 64 rows x CNT pairs, 8 KB) are staged once in LDS and read from there
+// (one uniform-address ds_read_b128 per row and pair) instead of through the scalar cache.  Pools with four or more
+// corrections per pass: a row needs 2 CNT scalars from 2 CNT different cache lines, scalar loads return out of order (one
+// batch in flight, ~1600 cycles under a saturated L2) and the pass was bound by that latency -- 14.3 ms per pass of 8
+// corrections at B = 512, n = 1000 against 5.2 ms of stream time.
+template <int UR, bool NT, int CNT, bool PRED, bool KL = false>
 __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, const double* __restrict__ Uall,
                                                 const double* __restrict__ Vall, const int* __restrict__ cnt_all, int N,
                                                 int ld, size_t sigma_stride, int rows_per_block,
@@ -419,8 +424,18 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
     const int c2 = blockIdx.x * 256 + threadIdx.x;
     const int row_begin = blockIdx.y * rows_per_block;
     const int row_end = min(N, row_begin + rows_per_block);
-    if (row_begin >= N || c2 >= ld2a) return;
+    if (row_begin >= N) return;   // (uniform)
     const double* __restrict__ Ub = Uall + (size_t)b * 2 * kCallV * ld;
+    __shared__ double2_t sh_Kl[KL ? 64 : 1][CNT];
+    if constexpr (KL) {   // rows fastest: consecutive threads read consecutive rows of one K vector
+        const int nrows = row_end - row_begin;   // <= 64 (launcher)
+        for (int e = threadIdx.x; e < nrows * CNT; e += 256) {
+            const int v = e / nrows, rr = e - v * nrows;
+            sh_Kl[rr][v] = double2_t{Ub[(size_t)(2 * v) * ld + row_begin + rr], Ub[(size_t)(2 * v + 1) * ld + row_begin + rr]};
+        }
+        __syncthreads();
+    }
+    if (c2 >= ld2a) return;
     const double2_t* __restrict__ Vb2 = reinterpret_cast<const double2_t*>(Vall + (size_t)b * 2 * kCallV * ld);
     double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + c2;
 
@@ -439,7 +454,9 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
     auto apply = [&](double2_t& x, int row) {
 #pragma unroll
         for (int v = 0; v < CNT; v++) {
-            const double k0 = Ub[(size_t)(2 * v) * ld + row], k1 = Ub[(size_t)(2 * v + 1) * ld + row];   // uniform -> s_load
+            double k0, k1;
+            if constexpr (KL) { const double2_t kk = sh_Kl[row - row_begin][v]; k0 = kk.x; k1 = kk.y; }
+            else { k0 = Ub[(size_t)(2 * v) * ld + row]; k1 = Ub[(size_t)(2 * v + 1) * ld + row]; }   // uniform -> s_load
             x.x = x.x - (k0 * g0[v].x + k1 * g1[v].x);
             x.y = x.y - (k0 * g0[v].y + k1 * g1[v].y);
         }
@@ -564,6 +581,9 @@ static void launch_rank2v_c(const PoolView& pv, const double* U, const double* V
 #define EKF_R2V_ARGS pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows, pred, pv.p.q_pose
     if (pred) {   // single filter with a folded prediction (small pool: temporal accesses)
         hipLaunchKernelGGL((k_rank2v<UR, false, CNT, true>), grid, dim3(256), 0, s, EKF_R2V_ARGS);
+    } else if (CNT >= 4 && rows >= 32 && rows <= 64) {   // (big pools: rows >= 32) K through LDS
+        if (nt) hipLaunchKernelGGL((k_rank2v<UR, true, CNT, false, true>), grid, dim3(256), 0, s, EKF_R2V_ARGS);
+        else hipLaunchKernelGGL((k_rank2v<UR, false, CNT, false, true>), grid, dim3(256), 0, s, EKF_R2V_ARGS);
     } else if (nt) {
         hipLaunchKernelGGL((k_rank2v<UR, true, CNT, false>), grid, dim3(256), 0, s, EKF_R2V_ARGS);
     } else {

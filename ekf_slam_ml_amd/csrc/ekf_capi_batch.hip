@@ -74,7 +74,7 @@ ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int non
 
 ekf_status ekf_batch_set_step_fused(ekf_batch_handle hb, int enable) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
-    hb->pool.step_fused = enable ? 1 : 0;
+    hb->pool.step_fused = enable < 0 ? 0 : enable > 2 ? 1 : enable;   // 2: always the one-launch form
     return EKF_OK;
 }
 
@@ -388,10 +388,34 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
             // (ekf_stepfused.hip); bit-identical to the four launches per measurement slot below
             EKFC(P.ensure_callfused());
             if (Nstep > 3 + 2 * kc_max) kc_max = (Nstep - 3) / 2;
-            if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
-            ekf::launch_pool_step_unknown(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
-                                          P.active_prefix ? 3 + 2 * P.touched_hwm : P.pv.N, P.ulog_assoc + (size_t)t * B * jmax,
-                                          P.cf_U, P.cf_V, P.corr_counter, P.stream);
+            // Big prefixes: the step kernel stops at the factor pairs and k_rank2v streams every covariance spread over
+            // the whole chip (one workgroup per filter streams its 32 MB at 4.6 TB/s pool-wide, k_rank2v at 6.4).  Chosen
+            // when the known counts are fresh (exact) and most of the launch bound is real work: k_rank2v covers the
+            // pool-wide bound Nstep for every filter, the one-launch form each filter's own prefix.
+            bool split = false;
+            if (fresh && Nstep >= 603 && P.step_fused == 1) {
+                double real = 0.0;
+                for (int b = 0; b < B; b++) {
+                    if (ct[b] <= 0) continue;
+                    const double nb = 3.0 + 2.0 * (kc[b] + ct[b] < n ? kc[b] + ct[b] : n);
+                    real += nb * nb;
+                }
+                const double span = P.active_prefix ? (double)Nstep : (double)P.pv.N;
+                split = real >= 0.7 * B * span * span;
+            }
+            if (split) {
+                pva.N = P.active_prefix ? Nstep : P.pv.N;
+                ekf::launch_pool_step_unknown(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
+                                              P.active_prefix ? 3 + 2 * P.touched_hwm : P.pv.N, P.ulog_assoc + (size_t)t * B * jmax,
+                                              P.cf_U, P.cf_V, P.corr_counter, P.stream, P.cf_cnt, ekf::rank2v_round_count(smax));
+                if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
+                ekf::launch_rank2v(pva, P.cf_U, P.cf_V, P.cf_cnt, smax, P.tuning, P.stream);
+            } else {
+                if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
+                ekf::launch_pool_step_unknown(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
+                                              P.active_prefix ? 3 + 2 * P.touched_hwm : P.pv.N, P.ulog_assoc + (size_t)t * B * jmax,
+                                              P.cf_U, P.cf_V, P.corr_counter, P.stream);
+            }
             if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
             k++;
             smax = 0;  // the step is done

@@ -448,9 +448,12 @@ void launch_assoc_meas(const PoolView& pv, const double* meas_j, const AssocRec*
 int rank2v_round_count(int vcount);   // corrections per pass, rounded up to an instantiated count of k_rank2v
 
 // one step of an unknown-association log for every filter of a pool in ONE launch, any prefix size (ekf_stepfused.hip):
-// jmax <= kCallV readings per filter; U, V: [B][2 kCallV][ld] scratch for the step's factor pairs
+// jmax <= kCallV readings per filter; U, V: [B][2 kCallV][ld] scratch for the step's factor pairs.  cnt_out != nullptr:
+// the kernel leaves the covariance pass to the caller (launch_rank2v over the same U, V with cnt_out as its counts,
+// zero_upto = rank2v_round_count(jmax)): big prefixes stream faster spread over the chip than one workgroup per filter.
 void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
-                              int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s);
+                              int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s,
+                              int* cnt_out = nullptr, int zero_upto = 0);
 
 // ---- one-launch prediction() + measurement() tick of a mid-size single filter, Sigma resident in LDS (ekf_coop.hip) ----
 struct CoopArgs {

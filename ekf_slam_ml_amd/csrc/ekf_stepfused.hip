@@ -29,10 +29,17 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
                                                                     const int* __restrict__ count, int jmax, int min_active,
                                                                     int* __restrict__ assoc_out, double* __restrict__ Uall,
                                                                     double* __restrict__ Vall,
-                                                                    unsigned long long* __restrict__ corr_counter) {
+                                                                    unsigned long long* __restrict__ corr_counter,
+                                                                    int* __restrict__ cnt_out, int zero_upto) {
+    // cnt_out == nullptr: the final pass runs here (one workgroup streams its filter's covariance).  Otherwise the step
+    // ends with the pairs in Uall / Vall (rows beyond the filter's pair count zero-filled up to `zero_upto` pairs) and
+    // cnt_out[b] pairs -- the caller streams all covariances with k_rank2v, which spreads every filter over the chip.
     const int b = blockIdx.x, tid = threadIdx.x;
     const int J = count ? count[b] : jmax;
-    if (J <= 0) return;  // uniform
+    if (J <= 0) {  // uniform
+        if (cnt_out && tid == 0) cnt_out[b] = 0;
+        return;
+    }
     const int n = pv.n, ld = pv.ld;
     // (no __restrict__: the pairs and the state are written and re-read by this workgroup, ordered by its barriers)
     double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
@@ -222,8 +229,16 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
         __syncthreads();
     }
 
+    if (cnt_out) {   // the pass is the caller's: unused pair rows become exact no-ops
+        for (int r = tid; r < ld; r += kStepThreads)
+            for (int v = pc; v < zero_upto; v++) {
+                Ub[(size_t)(2 * v) * ld + r] = 0.0; Ub[(size_t)(2 * v + 1) * ld + r] = 0.0;
+                Vb[(size_t)(2 * v) * ld + r] = 0.0; Vb[(size_t)(2 * v + 1) * ld + r] = 0.0;
+            }
+        if (tid == 0) cnt_out[b] = pc;
+    }
     // ---- ONE pass over the prefix: every element takes the step's corrections in order (k_rank2's expression) ----
-    if (pc > 0) {
+    if (pc > 0 && !cnt_out) {
         const int ld2n = ld >> 1, ld2a = (Nb + 1) >> 1;
         double2_t* S2 = reinterpret_cast<double2_t*>(Sg);
         const double2_t* V2 = reinterpret_cast<const double2_t*>(Vb);
@@ -284,9 +299,10 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
 }
 
 void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
-                              int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s) {
+                              int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s,
+                              int* cnt_out, int zero_upto) {
     hipLaunchKernelGGL(k_pool_step_unknown, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
-                       assoc_out, U, V, corr_counter);
+                       assoc_out, U, V, corr_counter, cnt_out, zero_upto);
 }
 
 }  // namespace ekf

@@ -145,8 +145,11 @@ ekf_status ekf_batch_set_call_fused(ekf_batch_handle hb, int enable);
 /* Pools, ekf_batch_run_unknown with at most 8 reading slots per step, discovered prefixes beyond the LDS-resident path
  * (3 + 2 * known > 104): one launch per STEP -- a workgroup per filter scores, decides and builds the gains of the step's
  * readings against the stored covariance minus the step's pending rank-2 pairs, and streams the filter's prefix ONCE at
- * the end of the step (enable != 0, default).  enable == 0: four launches per measurement slot (scores, decision, gain,
- * rank-2 stream).  Bit-identical. */
+ * the end of the step (enable == 1, default).  When the prefixes are big (launch bound N >= 603, known counts fresh, and
+ * at least 70 % of B * N^2 is discovered prefix) the step takes TWO launches instead: the same kernel stops at the factor
+ * pairs and one streaming pass over all filters (the rank-2 kernel's tiling, every filter spread over the chip) applies
+ * them -- enable == 2 keeps to the one-launch form.  enable == 0: four launches per measurement slot (scores, decision,
+ * gain, rank-2 stream).  All three bit-identical. */
 ekf_status ekf_batch_set_step_fused(ekf_batch_handle hb, int enable);
 /* Single filter, mid-size maps (104 < N = 3 + 2n, as long as N rows of Sigma spread over the device's CUs fit their
  * LDS: n up to about 700): ekf_predict + ekf_measure_known of one node tick run as ONE launch -- the rows of Sigma are

@@ -324,3 +324,44 @@ def test_step_fused_beyond_the_small_path(hip, oracle, surveyed):
         o, known, d = _oracle_replay(oracle, log, b, n, 0, T, o, known)
         assert np.array_equal(snap[0][0][:, b], d), f"filter {b}: decisions differ from the checker"
         assert_parity(snap[0][2][b], snap[0][3][b], o.state, o.cov, FP64_TOL, f"step-fused filter {b}")
+
+
+@pytest.mark.parametrize("surveyed_share", [1.0, 0.6])
+def test_step_with_a_separate_streaming_pass(hip, surveyed_share):
+    """Big prefixes on pools with fresh known counts (B >= 64, launch bound N >= 603): the step kernel stops at the
+    factor pairs and k_rank2v streams every covariance (two launches per step) -- against the one-launch form and the
+    four-launches-per-slot form, bit for bit: decisions, known counts, states, covariances.  Filters with ragged reading
+    counts (zero-filled pair rows), filters without readings in a step, and a pool in which 40 % of the filters have not
+    surveyed the map (the 70 % rule then keeps to one launch per step: the forms must still agree)."""
+    n, B, T = 320, 64, 6
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=777, half_extent=6.0, min_spacing=0.3, max_visible_dis=1.3, vmax=8,
+                          v_cmd=1.0, w_cmd=0.6)
+    log = synth.make_unknown_log(cfg)
+    cnt = log.count.copy()
+    cnt[2, ::5] = 0                      # some filters sit a step out
+    world = log.world
+    rng = np.random.default_rng(3)
+    init = (world[None] + rng.normal(0.0, 0.005, size=(B, n, 2))).reshape(B, 2 * n)
+    lm0 = np.full((2, B, 1), -1, dtype=np.int32)
+    known0 = np.where(np.arange(B) < surveyed_share * B, n, 0).astype(np.int32)
+    snap = []
+    for mode in (1, 2, 0, -64):   # -64: the two-launch form with 64-row workgroups (k_rank2v with K staged in LDS)
+        bt = hip.BatchEKF(B, n)
+        bt.set_step_fused(abs(mode) if mode >= 0 else 1)
+        if mode < 0:
+            bt.set_tuning(rows_per_block=-mode)
+        bt.upload_known_log(np.zeros((2, B, 2)), lm0, np.zeros((2, B, 1, 2)), init)
+        bt.run_known()
+        bt.set_known_counts(known0)
+        bt.upload_unknown_log(log.twist, cnt, log.meas_xy)
+        st = bt.run_unknown(0, T, time_kernels=True)
+        snap.append((bt.decisions().copy(), bt.known_counts().copy(), [bt.state(b) for b in (0, 7, B - 1)],
+                     [bt.cov(b) for b in (0, 7, B - 1)], bt.checksum(), st))
+        bt.close()
+    for other in (1, 2, 3):
+        assert np.array_equal(snap[0][0], snap[other][0]) and np.array_equal(snap[0][1], snap[other][1])
+        for k in range(3):
+            assert np.array_equal(snap[0][2][k], snap[other][2][k]) and np.array_equal(snap[0][3][k], snap[other][3][k])
+        assert np.allclose(np.array(snap[0][4]), np.array(snap[other][4]), rtol=1e-12)   # (atomic sums: order varies)
+        assert snap[0][5]["corrections"] == snap[other][5]["corrections"] > 200
+    assert snap[0][5]["rank2_launches"] == snap[1][5]["rank2_launches"] == T < snap[2][5]["rank2_launches"]

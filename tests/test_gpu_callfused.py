@@ -95,7 +95,7 @@ def test_call_fused_interleaved_with_association_and_snapshots(hip):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("B,n,vmax", [(7, 400, 5), (5, 130, 12), (10, 1000, 2)])
+@pytest.mark.parametrize("B,n,vmax", [(7, 400, 5), (5, 130, 12), (10, 1000, 2), (6, 401, 7), (3, 640, 16)])
 def test_call_fused_pool_bitwise_and_vs_checker(hip, oracle, B, n, vmax):
     """Pools: ragged visible counts across filters (some filters sit a pass out), several passes per call, split runs."""
     cfg = synth.SimConfig(n=n, steps=8, filters=B, seed=900 + n, half_extent=4.0, min_spacing=0.15,
@@ -108,6 +108,8 @@ def test_call_fused_pool_bitwise_and_vs_checker(hip, oracle, B, n, vmax):
     for cf in (True, False):
         bt = hip.BatchEKF(B, n)
         bt.set_call_fused(cf)
+        if n in (401, 640):
+            bt.set_tuning(rows_per_block=64 if n == 401 else 32)   # the big-pool form of the pass: K values staged in LDS
         bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
         bt.run_known(0, 3)
         st = bt.run_known(3, cfg.steps, time_kernels=True)
