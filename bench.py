@@ -656,6 +656,7 @@ def main():
             a_lm[t, :, :len(idx)] = idx
             a_z[t, :, :len(idx)] = lworld[idx][None] + rng.normal(0.0, 0.005, size=(Bl, len(idx), 2))
         a_init = (lworld[None] + rng.normal(0.0, 0.005, size=(Bl, n, 2))).reshape(Bl, 2 * n)
+        lb.set_tuning(a.rows, a.nt)
         lb.upload_known_log(np.zeros((Ta, Bl, 2)), a_lm, a_z, a_init)  # robot at rest at the origin: robot frame = world frame
         lb.set_call_fused(True)   # (the survey is untimed: 8 corrections per pass over Sigma)
         lb.run_known(0, Ta)

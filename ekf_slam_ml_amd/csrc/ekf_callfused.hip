@@ -406,7 +406,7 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
 // (At Sigma At^T + Q)(r, c) -- rows 1, 2 take a_r * row 0, columns 1, 2 take column 0 * a_c, the 3 x 3 pose block its own
 // formula (the structured arithmetic of k_predict, operation for operation) -- all from values this lane or its wave
 // neighbours hold: row 0 sits in the same row group as rows 1, 2, column 0 in lane 0 of strip 0.
-// KL: the K values of the workgroup's row block (<= 64 rows x CNT pairs, 8 KB) are staged once in LDS and read from there
+// KL: the K values of the workgroup's row block (<= 128 rows x CNT pairs, 16 KB) are staged once in LDS and read from there
 // (one uniform-address ds_read_b128 per row and pair) instead of through the scalar cache.  Pools with four or more
 // corrections per pass: a row needs 2 CNT scalars from 2 CNT different cache lines, scalar loads return out of order (one
 // batch in flight, ~1600 cycles under a saturated L2) and the pass was bound by that latency -- 14.3 ms per pass of 8
@@ -426,9 +426,9 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
     const int row_end = min(N, row_begin + rows_per_block);
     if (row_begin >= N) return;   // (uniform)
     const double* __restrict__ Ub = Uall + (size_t)b * 2 * kCallV * ld;
-    __shared__ double2_t sh_Kl[KL ? 64 : 1][CNT];
+    __shared__ double2_t sh_Kl[KL ? 128 : 1][CNT];
     if constexpr (KL) {   // rows fastest: consecutive threads read consecutive rows of one K vector
-        const int nrows = row_end - row_begin;   // <= 64 (launcher)
+        const int nrows = row_end - row_begin;   // <= 128 (launcher)
         for (int e = threadIdx.x; e < nrows * CNT; e += 256) {
             const int v = e / nrows, rr = e - v * nrows;
             sh_Kl[rr][v] = double2_t{Ub[(size_t)(2 * v) * ld + row_begin + rr], Ub[(size_t)(2 * v + 1) * ld + row_begin + rr]};
@@ -581,7 +581,7 @@ static void launch_rank2v_c(const PoolView& pv, const double* U, const double* V
 #define EKF_R2V_ARGS pv.sigma, U, V, cnt, pv.N, pv.ld, pv.sigma_stride, rows, pred, pv.p.q_pose
     if (pred) {   // single filter with a folded prediction (small pool: temporal accesses)
         hipLaunchKernelGGL((k_rank2v<UR, false, CNT, true>), grid, dim3(256), 0, s, EKF_R2V_ARGS);
-    } else if (CNT >= 4 && rows >= 32 && rows <= 64) {   // (big pools: rows >= 32) K through LDS
+    } else if (CNT >= 4 && rows >= 32 && rows <= 128) {   // (big pools: rows >= 32) K through LDS
         if (nt) hipLaunchKernelGGL((k_rank2v<UR, true, CNT, false, true>), grid, dim3(256), 0, s, EKF_R2V_ARGS);
         else hipLaunchKernelGGL((k_rank2v<UR, false, CNT, false, true>), grid, dim3(256), 0, s, EKF_R2V_ARGS);
     } else if (nt) {
@@ -607,6 +607,9 @@ void launch_rank2v(const PoolView& pv, const double* U, const double* V, const i
                                     : (strips * pv.N >= 256LL * 8 * 64 ? 64 : (strips * pv.N >= 256LL * 4 * 8 ? 8 : 4));
     if (pred && rows < 4) rows = 4;   // a folded prediction needs rows 0..2 inside one full row group (UR >= 4)
     const int c = rank2v_round_count(vcount);
+    // (with >= 4 corrections per pass a workgroup holds 2 waves/SIMD: 32 rows per workgroup stream at 5.76 TB/s, 64 at
+    // 5.52, 128 at 5.28 -- bench.py unknown_association_large_prefix --rows R)
+    if (c >= 4 && rows == 64 && t.rows_per_block <= 0) rows = 32;
     const bool big = rows >= 32;
     const bool u16 = big && t.group_rows != 8;
     switch (c) {
