@@ -155,11 +155,14 @@ def cf_trace(n=200, V=6):
     c, s = tr[0], tr[1]
     t0 = c[0]
     print(f"k_call_factors n={n} V={V} (cycles from kernel start; 2400 cycles = 1 us)")
-    print(f"  setup: control {c[1] - t0:.0f}, slices {s[1] - t0:.0f}; after first barrier {c[2] - t0:.0f}")
-    for t in range(V + 1):
+    print(f"  setup: control {c[1] - t0:.0f}, slices {s[1] - t0:.0f}; terms + gains of correction 0 done {c[2] - t0:.0f}")
+    # per correction t (ekf_callfused.hip): barrier | wave 0: terms_h(t+1) || wave 1: core block update(t) || slices: factors
+    # + panels(t) | barrier | wave 0: terms_s(t+1) + core gains(t+1)
+    for t in range(V):
         b = 3 + 5 * t
-        print(f"  step {t}: control terms {c[b] - t0:8.0f} KG {c[b + 1] - t0:8.0f} core update {c[b + 2] - t0:8.0f} | slice done {s[b + 2] - t0:8.0f} | "
-              f"at barrier control {c[b + 3] - t0:8.0f} slices {s[b + 3] - t0:8.0f} | released {c[b + 4] - t0:8.0f}")
+        last = t + 1 == V
+        print(f"  correction {t}: released {c[b] - t0:8.0f} | control: next terms (h) {c[b + 1] - t0:8.0f} | slices: factors + panels "
+              f"{s[b + 1] - t0:8.0f}" + ("" if last else f" | second barrier {c[b + 2] - t0:8.0f} | next S, gains {c[b + 3] - t0:8.0f}"))
     print(f"  end {c[60] - t0:.0f}")
 
 
