@@ -46,3 +46,28 @@ def test_launcher_rank_count_mismatch_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"] + ARGS, capture_output=True,
                        text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0 and "--gpus 4 but the launcher started 2" in (r.stderr + r.stdout)
+
+
+def test_rccl_reductions_on_the_device():
+    """The collectives of the N > 1 job on the RCCL backend itself ("nccl" on ROCm): a single-rank communicator on the
+    test box's GPU runs the very calls bench.py makes at N > 1 -- fp64 MAX / SUM all-reduces on device tensors, the
+    barrier, the pose all-gather."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["EKF_ROOT"])
+import torch, torch.distributed as dist
+from ekf_slam_ml_amd import shard
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dist.barrier()
+w, c, f = shard.reduce_throughput(1.25, 1000.0, 500.0, device="cuda")
+assert (w, c, f) == (1.25, 1000.0, 500.0), (w, c, f)
+assert shard.count_ranks(device="cuda") == 1
+p = shard.gather_poses([[0.1, 0.2, 0.3], [1.0, 2.0, 3.0]], device="cuda")
+assert p.shape == (2, 3) and p[1, 2] == 3.0
+dist.destroy_process_group()
+print("rccl ok")
+'''
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", EKF_ROOT=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
