@@ -468,12 +468,17 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
         const int strips = (pv.ld / 2 + kStripCols2 - 1) / kStripCols2;
         int row_blocks = 1;
         while ((long long)pv.B * strips * row_blocks < 1024 && pv.N / (row_blocks * 2) >= 512) row_blocks *= 2;
-        static int attr_ok = -1;   // dynamic LDS beyond 64 KB has to be allowed per kernel (once)
-        if (attr_ok < 0)
-            attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kStripCols2 * 16) == hipSuccess &&
-                      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kStripCols2 * 16) == hipSuccess;
+        // dynamic LDS beyond 64 KB has to be allowed per kernel and per device (once each)
+        static int attr_state[64];   // 0: not tried, 1: ok, 2: refused -> plain form
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (attr_state[dev] == 0)
+            attr_state[dev] = (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kStripCols2 * 16) == hipSuccess &&
+                               hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kStripCols2 * 16) == hipSuccess)
+                                  ? 1 : 2;
+        const bool attr_ok = attr_state[dev] == 1;
         if (attr_ok && (forced || (long long)pv.B * strips * row_blocks >= 512)) {
             const int rows = (((pv.N + row_blocks - 1) / row_blocks) + 7) & ~7;
             row_blocks = (pv.N + rows - 1) / rows;
