@@ -307,6 +307,7 @@ constexpr int kStripCols2 = 128;   // double2 columns per strip: lane l holds co
 template <bool NT>
 __device__ __forceinline__ void fl_load(double2_t (&a)[8][2], const double2_t* __restrict__ col, int r, int last, int ld2n,
                                         bool live0, bool live1) {
+    const double2_t zero2 = {0.0, 0.0};
     if (live0) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -314,6 +315,9 @@ __device__ __forceinline__ void fl_load(double2_t (&a)[8][2], const double2_t* _
             if constexpr (NT) a[u][0] = __builtin_nontemporal_load(col + row * ld2n);
             else a[u][0] = col[row * ld2n];
         }
+    } else {   // (lanes past the last column: defined values, never stored)
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u][0] = zero2;
     }
     if (live1) {
 #pragma unroll
@@ -322,6 +326,9 @@ __device__ __forceinline__ void fl_load(double2_t (&a)[8][2], const double2_t* _
             if constexpr (NT) a[u][1] = __builtin_nontemporal_load(col + row * ld2n + 64);
             else a[u][1] = col[row * ld2n + 64];
         }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u][1] = zero2;
     }
 }
 template <bool NT>
