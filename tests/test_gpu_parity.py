@@ -584,3 +584,37 @@ def test_maximum_map_size_n5000(hip, oracle):
         assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "n = 5000")
         f.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("n", [5, 150, 800])
+def test_empty_association_call_and_all_dropped_readings(hip, oracle, n):
+    """data_association() with no readings (a scan without clusters, landmarks.cpp:141 hands over an empty vector) and with
+    readings that are all dropped (between the gates of a full known_list): no change of state, covariance or known_list
+    on any of the three paths (LDS-resident, two launches per reading, once per call), the pending prediction still
+    takes effect, and the filter keeps working afterwards."""
+    cfg = synth.SimConfig(n=n, steps=6, half_extent=6.0, min_spacing=0.25, max_visible_dis=2.0, vmax=4, seed=60 + n)
+    log = synth.make_known_log(cfg)
+    f, o = hip.EKF_SLAM(n), oracle.OracleEKF(n, oracle.STRUCTURED)
+    f.set_active_prefix(False)
+    for t in range(3):
+        sensor, vis = log.expand_step(t)
+        f.prediction(log.twist[t, 0]); o.prediction(*log.twist[t, 0])
+        f.measurement(sensor, vis); o.measurement(sensor, vis)
+    kf, ko = np.ones(n, dtype=np.uint8), np.ones(n, dtype=np.uint8)
+    f.prediction((0.03, 0.02)); o.prediction(0.03, 0.02)
+    a = f.data_association(np.zeros((0, 2)), kf)
+    b = o.data_association(np.zeros((0, 2)), ko)
+    assert a.size == 0 and b.size == 0 and kf.all()
+    assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "empty call")
+    # readings far from every landmark with the map full: 10 <= d for all i -> idx = known_count = n -> ignored (:318, :330)
+    far = np.array([[400.0, 300.0], [-350.0, 420.0]])
+    f.prediction((0.0, 0.01)); o.prediction(0.0, 0.01)
+    a, b = f.data_association(far, kf), o.data_association(far, ko)
+    assert np.array_equal(a, b) and np.all(a == -1)
+    assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "all dropped")
+    for t in range(3, 6):
+        sensor, vis = log.expand_step(t)
+        f.prediction(log.twist[t, 0]); o.prediction(*log.twist[t, 0])
+        f.measurement(sensor, vis); o.measurement(sensor, vis)
+    assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "afterwards")
+    f.close()
