@@ -12,7 +12,10 @@ N_SCEN = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 for seed in range(N_SCEN):
     rng = np.random.default_rng(70000 + seed)
     B, n, T, J = int(rng.integers(1, 7)), int(rng.integers(3, 91)), int(rng.integers(4, 26)), int(rng.integers(1, 7))
-    world = rng.uniform(-2.5, 2.5, size=(max(n, 8), 2))
+    heavy = seed % 20 == 19   # big prefixes on a pool with fresh known counts: the two-launch step (k_rank2v, K in LDS)
+    if heavy:
+        B, n, T, J = int(rng.integers(64, 72)), int(rng.integers(300, 340)), int(rng.integers(3, 6)), int(rng.integers(2, 9))
+    world = rng.uniform(-2.5, 2.5, size=(max(n, 8), 2)) * (3.0 if heavy else 1.0)
     twist = np.stack([rng.normal(0, 0.2, (T, B)), rng.normal(0.05, 0.03, (T, B))], axis=2)
     count = rng.integers(0, J + 1, size=(T, B)).astype(np.int32)
     meas = np.zeros((T, B, J, 2))
@@ -26,8 +29,14 @@ for seed in range(N_SCEN):
             meas[t, b] = np.stack([c * d[:, 0] + s * d[:, 1], -s * d[:, 0] + c * d[:, 1]], axis=1) + rng.normal(0, 0.004, (J, 2))
     bt = hip.BatchEKF(B, n)
     bt.set_small_map_path(bool(rng.integers(0, 2)))
-    bt.set_step_fused(bool(rng.integers(0, 2)))
+    bt.set_step_fused(int(rng.integers(0, 3)))   # four launches per slot / automatic / always one launch per step
     bt.set_active_prefix(bool(rng.integers(0, 2)))
+    surveyed = heavy and bool(rng.integers(0, 2))
+    init = (world[:n][None] + rng.normal(0, 0.004, (B, n, 2))).reshape(B, 2 * n) if surveyed else None
+    if surveyed:   # known_list all true from the start: the map comes from a first known-association call
+        bt.upload_known_log(np.zeros((1, B, 2)), np.full((1, B, 1), -1, dtype=np.int32), np.zeros((1, B, 1, 2)), init)
+        bt.run_known()
+        bt.set_known_counts(n)
     bt.upload_unknown_log(twist, count, meas)
     cut = int(rng.integers(0, T + 1))
     bt.run_unknown(0, cut); bt.run_unknown(cut, T)
@@ -37,6 +46,9 @@ for seed in range(N_SCEN):
         f = hip.EKF_SLAM(n)
         f.set_fused_correction(bool(rng.integers(0, 2)))
         k = np.zeros(n, dtype=np.uint8)
+        if surveyed:
+            f.prediction((0.0, 0.0)); f.measurement(init[b], np.zeros(n, dtype=np.uint8))
+            k[:] = 1
         for t in range(T):
             f.prediction(twist[t, b])
             a = f.data_association(meas[t, b, :count[t, b]], k)
