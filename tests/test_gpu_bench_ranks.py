@@ -13,6 +13,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
 ARGS = ["--steps", "3", "--warmup", "1", "--filters", "96", "--landmarks", "300", "--only-main", "--no-cpu-baseline"]
 
 
@@ -28,7 +35,7 @@ def test_two_ranks_through_torchrun_aggregate_like_one():
                          text=True, timeout=600, env=env, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"),
+                          "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"),
                           "--gpus", "2"] + ARGS, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert two.returncode == 0, two.stderr[-2000:]
     a, b = _line(one.stdout), _line(two.stdout)
@@ -68,6 +75,6 @@ assert p.shape == (2, 3) and p[1, 2] == 3.0
 dist.destroy_process_group()
 print("rccl ok")
 '''
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", EKF_ROOT=ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), EKF_ROOT=ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
