@@ -284,9 +284,17 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         EKFC(checked_launch());
         return associate_finish(P, known_count, J, known, assoc_out);
     }
-    EKFC(P.upload(P.meas_dev, meas_xy, sizeof(double) * 2 * J));
+    // The two-launch path per reading (k_maha + k_associate_fused) takes its readings BY VALUE in the kernel arguments;
+    // every other path reads them from the device: staged on first need (one host-to-device copy per call, ~5 us).
+    bool staged = false;
+    auto need_dev = [&]() -> ekf_status {
+        if (!staged) EKFC(P.upload(P.meas_dev, meas_xy, sizeof(double) * 2 * J));
+        staged = true;
+        return EKF_OK;
+    };
     if (!delayed && P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && n <= 128) {
         // small map: scores, decisions and corrections of all J measurements in one LDS-resident launch
+        EKFC(need_dev());
         P.alt_synced = false;
         ekf::launch_small_associate(P.pv, P.meas_dev, J, known_count, P.assoc_out_dev, P.pred_pending, P.pred_dth,
                                     P.pred_dx, P.stream);
@@ -305,6 +313,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         if (P.touched_hwm > m) m = P.touched_hwm;
         const int Nb = 3 + 2 * m;
         if (!delayed && P.small_path && P.active_prefix && n > 0 && Nb <= ekf::small_max_dim()) {
+            EKFC(need_dev());
             P.alt_synced = false;
             ekf::PoolView pva = P.pv;
             pva.N = Nb;
@@ -335,6 +344,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     // launch is cheap and two launches per reading win (configs[2]'s discovery run: 12.7 k vs 10.5 k steps/s).
     if (!delayed && P.pv.B == 1 && P.call_fused_ok() && active_dim(0) >= 1400) {
         EKFC(P.ensure_callfused());
+        EKFC(need_dev());
         if (!P.terms) EKFC(P.dalloc(&P.terms, (size_t)(n > 0 ? n : 1) * 16));
         P.alt_synced = false;
         for (int j0 = 0; j0 < J; j0 += ekf::kCallV) {
@@ -368,7 +378,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         }
         if (P.fused_ok()) {  // two launches per measurement: scores (+ correction terms), then decision + correction
             EKFC(P.ensure_alt());
-            const ekf::MeasSrc msf{mj, 2, nullptr, 0, P.terms};
+            ekf::MeasSrc msf{nullptr, 2, nullptr, 0, P.terms, meas_xy[2 * j], meas_xy[2 * j + 1], 1};
             EKFC(P.prof_begin(1));
             ekf::launch_maha(P.pv, msf, P.scores, -1, known_count + j < n ? known_count + j : n, P.stream);
             EKFC(P.prof_end());
@@ -383,6 +393,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
             std::swap(P.pv.assoc, P.assoc_alt);
             continue;
         }
+        EKFC(need_dev());
         const ekf::MeasSrc ms{mj, 2, nullptr, 0};
         EKFC(P.prof_begin(1));
         const ekf::Pending pend = P.pending();

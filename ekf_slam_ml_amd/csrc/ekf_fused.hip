@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_associate_fused(PoolView pv, MeasSrc ms
     const bool lead = blockIdx.x == 0 && blockIdx.y == 0;
     const double2_t* __restrict__ cur2 = reinterpret_cast<const double2_t*>(cur);
     double2_t* __restrict__ nxt2 = reinterpret_cast<double2_t*>(nxt);
-    const double* meas = ms.xy + (size_t)b * ms.stride;
+    const double meas[2] = {ms.by_value ? ms.vx : ms.xy[(size_t)b * ms.stride], ms.by_value ? ms.vy : ms.xy[(size_t)b * ms.stride + 1]};
 
     __shared__ double sh_d[4];
     __shared__ int sh_i[4];

@@ -646,7 +646,7 @@ __global__ void k_touch_all(PoolView pv) {
 __global__ __launch_bounds__(256) void k_maha(PoolView pv, MeasSrc ms, double* scores, int m_override, Pending pend) {
     const int b = blockIdx.y;
     if (ms.count && ms.j >= ms.count[b]) return;  // this filter has no measurement in this slot
-    const double* meas = ms.xy + (size_t)b * ms.stride;
+    const double meas[2] = {ms.by_value ? ms.vx : ms.xy[(size_t)b * ms.stride], ms.by_value ? ms.vy : ms.xy[(size_t)b * ms.stride + 1]};
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int i = blockIdx.x * 4 + wave;
     const int M = m_override >= 0 ? m_override : pv.assoc[b].known_count;

@@ -89,6 +89,10 @@ struct MeasSrc {
     int j;
     double* terms;      // nullable, single filter: k_maha keeps {H[2][5], S^-1[2][2], nu0, nu1 (unwrapped)} of every
                         // scored landmark here ([n][16]) so that the correction of the winner need not rebuild them
+    // by_value != 0 (single filter): the reading travels in the kernel arguments (vx, vy) -- no staging copy in front of
+    // the call; xy is not read
+    double vx, vy;
+    int by_value;
 };
 
 struct PoolView {
