@@ -135,6 +135,7 @@ def leg_configs_1(device, cores, steps=2000, warm=100, want_cpu=True):
         f.close()
         return dt, prof, st
 
+    run(False)   # untimed pass: first launches of every kernel instantiation of the path (code-object loading, clocks)
     dt, _, st_gpu = run(False)
     _, prof, _ = run(True)
     corr = int((log.lm_idx[warm:] >= 0).sum())
@@ -195,27 +196,34 @@ def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
     out = {"workload": f"BASELINE.json configs[2]: 1 filter, n={n} (N={N}), unknown association, J<=8 shuffled readings per "
                        f"step, one ekf_predict + ekf_associate per step through the C ABI (ctypes loop)"}
 
-    # (a) discovery run
+    # (a) discovery run (an untimed pass first: the path changes kernels as the map grows -- LDS-resident step kernel,
+    # then two launches per reading -- and the first launch of every instantiation loads its code object)
     warm = 50
-    f = capi.EKF_SLAM(n, device=device)
-    known = np.zeros(n, dtype=np.uint8)
-    for t in range(warm):
-        f.prediction(log.twist[t, 0]); f.data_association(meas[t], known)
-    f.sync()
-    t0 = time.perf_counter()
-    nm = nc = 0
-    scores = 0
-    for t in range(warm, steps):
-        kc = int(known.sum())
-        f.prediction(log.twist[t, 0]); a = f.data_association(meas[t], known)
-        nm += len(a); nc += int((a >= 0).sum())
-        scores += len(a) * kc  # lower bound (known_count grows inside the call)
-    f.sync()
-    dt = time.perf_counter() - t0
+
+    def discover():
+        f = capi.EKF_SLAM(n, device=device)
+        known = np.zeros(n, dtype=np.uint8)
+        for t in range(warm):
+            f.prediction(log.twist[t, 0]); f.data_association(meas[t], known)
+        f.sync()
+        t0 = time.perf_counter()
+        nm = nc = 0
+        scores = 0
+        for t in range(warm, steps):
+            kc = int(known.sum())
+            f.prediction(log.twist[t, 0]); a = f.data_association(meas[t], known)
+            nm += len(a); nc += int((a >= 0).sum())
+            scores += len(a) * kc  # lower bound (known_count grows inside the call)
+        f.sync()
+        dt = time.perf_counter() - t0
+        f.close()
+        return dt, nm, nc, scores, known
+
+    discover()
+    dt, nm, nc, scores, known = discover()
     out["discovery"] = {"value": (steps - warm) / dt, "unit": "filter steps/s", "measurements_per_s": nm / dt,
                         "corrections_per_s": nc / dt, "scores_per_s": scores / dt, "known_landmarks_end": int(known.sum()),
                         "steps": steps - warm}
-    f.close()
 
     # (b) full map: phase A builds the map through the known-association API (first call initialises all n landmarks,
     # second call corrects all n at full width), phase B is data_association with known_list all true.
@@ -235,6 +243,10 @@ def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
         g.sync()
         return g
 
+    rng = np.random.default_rng(33); g = build(False)
+    for t in range(10):   # untimed, on a throw-away object: first launches of the full-map kernels
+        g.prediction(log.twist[t, 0]); g.data_association(meas[t], np.ones(n, dtype=np.uint8))
+    g.close()
     rng = np.random.default_rng(33); g = build(False)
     snap_state, snap_cov = (g.state, g.cov) if want_cpu else (None, None)
     kn = np.ones(n, dtype=np.uint8)
