@@ -618,3 +618,27 @@ def test_empty_association_call_and_all_dropped_readings(hip, oracle, n):
         f.measurement(sensor, vis); o.measurement(sensor, vis)
     assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "afterwards")
     f.close()
+
+
+@pytest.mark.parametrize("n,call_fused", [(120, True), (120, False), (700, True)])
+def test_degenerate_geometry_on_the_streaming_paths(hip, oracle, n, call_fused):
+    """The same division by zero (landmark exactly at the robot position, ekf_slam.cpp:160-166) beyond the LDS-resident
+    path: once-per-call and once-per-landmark measurement() must produce the reference's NaN pattern too -- in the state, in
+    the covariance, and in what a later healthy correction of ANOTHER landmark makes of them (NaN spreads through K)."""
+    f, o = hip.EKF_SLAM(n), oracle.OracleEKF(n, oracle.STRUCTURED)
+    f.set_call_fused(call_fused)
+    rng = np.random.default_rng(n)
+    sensor = rng.uniform(-3, 3, size=2 * n)
+    sensor[0:2] = 0.0                       # landmark 0 is initialised AT the robot pose
+    none = np.zeros(n, dtype=np.uint8)
+    f.measurement(sensor, none); o.measurement(sensor, none)
+    vis = none.copy(); vis[5] = 1           # a healthy correction first
+    f.prediction((0.0, 0.0)); o.prediction(0.0, 0.0)
+    f.measurement(sensor, vis); o.measurement(sensor, vis)
+    assert not np.isnan(f.state).any()
+    vis = none.copy(); vis[0] = 1; vis[7] = 1   # the degenerate landmark, then another one in the same call
+    f.measurement(sensor, vis); o.measurement(sensor, vis)
+    assert np.isnan(f.state).any()
+    assert np.array_equal(np.isnan(f.state), np.isnan(o.state))
+    assert np.array_equal(np.isnan(f.cov), np.isnan(o.cov))
+    f.close()
