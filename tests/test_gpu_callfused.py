@@ -198,3 +198,28 @@ def test_call_fused_data_association_bitwise_and_vs_checker(hip, oracle, n, vmax
                 o.set_init_flag(1)
                 o.prediction(0.01, 0.01); o.measurement(np.tile(m[0], n), vis)
         assert_parity(res[0][0], res[0][1], o.state, o.cov, FP64_TOL, "call-fused data_association vs checker")
+
+
+@pytest.mark.parametrize("call_fused", [True, False])
+def test_a_filter_full_of_nan_leaves_its_pool_neighbours_alone(hip, call_fused):
+    """Filters of a pool share nothing (ekf_slam.hpp:61-65): one filter fed a non-finite reading turns to NaN (the
+    reference has no guards: arithmetic faults propagate silently); its neighbours must come out bit-identical to a run
+    in which that filter is healthy -- factor rows, counts and passes are per filter."""
+    B, n, T = 5, 130, 6
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=17, half_extent=4.0, min_spacing=0.2, max_visible_dis=2.0, vmax=4)
+    log = synth.make_known_log(cfg)
+    assert (log.lm_idx[1, 2] >= 0).any()
+    res = []
+    for poisoned in (True, False):
+        z = log.z_xy.copy()
+        if poisoned:
+            z[1, 2, 0, 0] = np.nan      # filter 2, step 1, first visible landmark
+        bt = hip.BatchEKF(B, n)
+        bt.set_call_fused(call_fused)
+        bt.upload_known_log(log.twist, log.lm_idx, z, log.init_xy)
+        bt.run_known(0, T)
+        res.append(([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)]))
+        bt.close()
+    assert np.isnan(res[0][0][2]).any() and np.isnan(res[0][1][2]).any() and not np.isnan(res[1][0][2]).any()
+    for b in (0, 1, 3, 4):
+        assert np.array_equal(res[0][0][b], res[1][0][b]) and np.array_equal(res[0][1][b], res[1][1][b]), f"filter {b}"
