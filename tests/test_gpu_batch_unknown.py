@@ -365,3 +365,41 @@ def test_step_with_a_separate_streaming_pass(hip, surveyed_share):
         assert np.allclose(np.array(snap[0][4]), np.array(snap[other][4]), rtol=1e-12)   # (atomic sums: order varies)
         assert snap[0][5]["corrections"] == snap[other][5]["corrections"] > 200
     assert snap[0][5]["rank2_launches"] == snap[1][5]["rank2_launches"] == T < snap[2][5]["rank2_launches"]
+
+
+@pytest.mark.parametrize("B,n,mode", [(64, 320, 1), (6, 150, 1), (6, 150, 0), (5, 40, 1)])
+def test_a_non_finite_reading_stays_inside_its_filter(hip, B, n, mode):
+    """A NaN reading in ONE filter of an unknown-association run (the reference has no guards: it propagates silently
+    through that filter's state and covariance) must leave every other filter of the pool bit-identical -- on the
+    LDS-resident step kernel (n = 40), the one-launch step, the two-launch step (B = 64: fresh known counts) and the
+    four-launch form."""
+    T = 5
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=31 + n, half_extent=5.0, min_spacing=0.3, max_visible_dis=1.4, vmax=6,
+                          v_cmd=1.0, w_cmd=0.6)
+    log = synth.make_unknown_log(cfg)
+    assert log.count[2, 1] >= 1
+    rng = np.random.default_rng(8)
+    init = (log.world[None] + rng.normal(0.0, 0.005, size=(B, n, 2))).reshape(B, 2 * n)
+    lm0 = np.full((2, B, 1), -1, dtype=np.int32)
+    res = []
+    for poisoned in (True, False):
+        meas = log.meas_xy.copy()
+        if poisoned:
+            meas[2, 1, 0, 1] = np.nan        # filter 1, step 2, first reading
+        bt = hip.BatchEKF(B, n)
+        bt.set_step_fused(mode)
+        if n >= 150:     # big prefixes from the start: the map is surveyed first
+            bt.upload_known_log(np.zeros((2, B, 2)), lm0, np.zeros((2, B, 1, 2)), init)
+            bt.run_known()
+            bt.set_known_counts(n)
+        bt.upload_unknown_log(log.twist, log.count, meas)
+        bt.run_unknown(0, T)
+        res.append((bt.decisions().copy(), [bt.state(b) for b in range(B)], [bt.cov(b) for b in range(min(B, 8))]))
+        bt.close()
+    assert np.isnan(res[0][1][1]).any() or not np.array_equal(res[0][0][:, 1], res[1][0][:, 1])   # the reading mattered
+    for b in range(B):
+        if b == 1:
+            continue
+        assert np.array_equal(res[0][0][:, b], res[1][0][:, b]) and np.array_equal(res[0][1][b], res[1][1][b]), f"filter {b}"
+        if b < 8:
+            assert np.array_equal(res[0][2][b], res[1][2][b]), f"filter {b} covariance"
