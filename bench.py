@@ -477,9 +477,12 @@ def main():
         if rank == 0:
             kk = float(a.delayed_k)
             Nf = float(N)
-            # declared algorithmic bytes per correction: flush share (Sigma read+write + factor reads) +
-            # average factor read of the gain step + base gathers + factor/state append
-            per_corr = (16.0 * Nf * Nf + 32.0 * Nf * kk) / kk + 16.0 * Nf * (kk - 1.0) + 14.0 * 8.0 * Nf
+            # declared algorithmic bytes per correction: flush share (Sigma read+write + factor reads) + average
+            # factor read of the gain step + base gathers + factor/state append.  The two corrections of a step share
+            # ONE launch (k_gain_delayed_pair): the pending factors (0, 4, ..., 2k - 4 vectors of 16 N bytes: k - 2 on
+            # average) and the 7 rows + 7 columns of the two landmarks are read once per PAIR; 4 rows of 8 N bytes are
+            # appended per correction.  (One launch per landmark: 16 N (k - 1) + 112 N for these terms.)
+            per_corr = (16.0 * Nf * Nf + 32.0 * Nf * kk) / kk + 0.5 * 16.0 * Nf * (kk - 2.0) + (0.5 * 14.0 + 4.0) * 8.0 * Nf
             delayed = {"value": dcorr / dwall, "unit": "update steps/s", "corrections_per_flush": a.delayed_k,
                        "steps": Kd, "ms_per_step": dwall / Kd * 1e3, "flushes": sd["rank2_launches"],
                        "flush_avg_ms": sd["rank2_ms"] / max(sd["rank2_launches"], 1),
@@ -489,7 +492,8 @@ def main():
                        "frac_of_8TBps": dcorr / world * per_corr / dwall / 1e9 / HBM_PEAK_GBS,
                        "speedup_vs_eager": (dcorr / dwall) / (corr / wall),
                        "note": "Sigma = Sigma_base - sum K_j (H Sigma)_j kept as factors, rewritten once per "
-                               "k corrections; results equal the eager path to rounding (tests/test_gpu_delayed.py)"}
+                               "k corrections; the two corrections of a step share one gain launch; results equal the "
+                               "eager path to rounding (tests/test_gpu_delayed.py)"}
             if Kd == K:
                 dstate = np.stack([bt.state(b) for b in range(min(B, 4))])
                 delayed["max_abs_state_diff_vs_eager"] = float(np.abs(dstate - eager_state[:len(dstate)]).max())

@@ -34,7 +34,7 @@ SYMBOLS = [
     "ekf_batch_create", "ekf_batch_destroy", "ekf_batch_reset", "ekf_batch_device_bytes",
     "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_upload_unknown_log", "ekf_batch_run_unknown",
     "ekf_batch_get_known_counts", "ekf_batch_get_decisions", "ekf_batch_set_active_prefix", "ekf_batch_set_small_map_path", "ekf_set_fused_correction", "ekf_batch_get_state", "ekf_batch_get_cov",
-    "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
+    "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning", "ekf_batch_set_delayed_pairing",
     "ekf_set_update_mode", "ekf_batch_set_update_mode",
     "ekf_default_sim_params", "ekf_batch_simulate_known_log", "ekf_batch_download_log", "ekf_batch_mc_stats",
     "ekf_circle_fit_scans", "ekf_normalize_angles",
@@ -162,6 +162,7 @@ def load():
         "ekf_batch_get_poses": [h, _dp],
         "ekf_batch_checksum": [h, _dp],
         "ekf_batch_set_tuning": [h, C.c_int, C.c_int, C.c_int],
+        "ekf_batch_set_delayed_pairing": [h, C.c_int],
         "ekf_set_update_mode": [h, C.c_int, C.c_int],
         "ekf_batch_set_update_mode": [h, C.c_int, C.c_int],
         "ekf_batch_simulate_known_log": [h, C.POINTER(SimParams), _dp, C.c_int, C.c_int],
@@ -552,6 +553,10 @@ class BatchEKF:
     def set_call_fused(self, enable=True):
         """every measurement() call of the pool as factor panels + ONE pass over Sigma (exact; default off for pools)"""
         _check(self._lib.ekf_batch_set_call_fused(self._h, int(bool(enable))))
+
+    def set_delayed_pairing(self, enable=True):
+        """delayed mode: two consecutive log slots of a step per launch (default) / one launch per landmark"""
+        _check(self._lib.ekf_batch_set_delayed_pairing(self._h, int(bool(enable))))
 
     def set_step_fused(self, enable=True):
         """unknown association beyond the LDS-resident path: True / 1 = one launch per step, two for big prefixes

@@ -91,6 +91,12 @@ ekf_status ekf_batch_rank2_variant(ekf_batch_handle hb, int* group_rows, int* no
     return EKF_OK;
 }
 
+ekf_status ekf_batch_set_delayed_pairing(ekf_batch_handle hb, int enable) {
+    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
+    hb->pool.delayed_pair = enable ? 1 : 0;
+    return EKF_OK;
+}
+
 ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections, int symmetric_gather) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
     return hb->pool.set_update_mode(max_pending_corrections, symmetric_gather);
@@ -156,7 +162,8 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
     const bool callf = !delayed && P.call_fused_ok();
     if (callf) EKFC(P.ensure_callfused());
     // worst-case number of covariance passes (rank-2 launches, or flushes in delayed mode) for the events
-    const size_t max_passes = delayed ? launches / (size_t)(P.pend_cap / 2) + 2 : launches;
+    // (paired slots flush when FOUR rows no longer fit: up to one flush per two corrections for tiny k)
+    const size_t max_passes = delayed ? launches / (size_t)(P.pend_cap >= 4 ? (P.pend_cap / 2 > 2 ? P.pend_cap / 2 - 1 : 1) : 1) + 2 : launches;
     hipEvent_t* ev = nullptr;
     if (time_kernels && launches) {
         ev = P.events(2 * max_passes);
@@ -225,6 +232,13 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
             if (P.slot_active[(size_t)t * vmax + v] == 0) continue;
             src.v = v;
             if (delayed) {
+                // two consecutive slots in one launch: the pending factor rows are read once for both corrections
+                if (P.delayed_pair && P.pend_cap >= 4 && v + 1 < vmax && P.slot_active[(size_t)t * vmax + v + 1] > 0) {
+                    if (P.pend_count + 4 > P.pend_cap) EKFC(timed_flush());
+                    EKFC(P.correct_pair(src));
+                    v++;
+                    continue;
+                }
                 if (P.pend_count + 2 > P.pend_cap) EKFC(timed_flush());
                 EKFC(P.correct(src));
             } else {

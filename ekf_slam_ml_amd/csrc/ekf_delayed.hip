@@ -191,6 +191,239 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
 }
 
 // ---------------------------------------------------------------------------------------------
+// TWO consecutive corrections of a measurement() call in delayed mode (log slots v and v + 1 of a known-association
+// step) in one launch: every lane reads the pending factor rows of its indices ONCE for both corrections -- the
+// O(kN) factor read is the dominant traffic of the delayed gain step (k_gain_delayed reads it per correction).
+// Correction 2 sees the covariance after correction 1 through the 7 x 7 core block Sigma[C, C], C = c5(lm1) u c5(lm2),
+// which every workgroup rebuilds from the base entries and the pending vectors at those 7 indices (tiny) and carries
+// through correction 1 itself (the panel idea of ekf_callfused.hip): K1 and G1 at the indices of landmark 2, the
+// landmark's position after the first state update, S2.  The lanes then build K1, G1 for their indices, apply the first
+// correction to their 2 x 5 entries of landmark 2's rows / columns, and build K2, G2.  Both pairs are appended
+// (rows count .. count + 3; a filter whose second slot is empty appends a zero pair, one whose slots are both empty two).
+// Pose: the stale pose of the call (snap) for both corrections (ekf_slam.cpp:109-111).  grid (ceil(ld/512), B).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc src, Pending pend,
+                                                           double* __restrict__ state_out) {
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int N = pv.N, ld = pv.ld;
+    const int rc = pend.count;
+    __shared__ double sh_U7[7 * kMaxPending];
+    __shared__ double sh_V7[7 * kMaxPending];
+    __shared__ double sh_C[7][8];                 // core block Sigma[C, C] as it stands before the call's corrections
+    __shared__ double sh_H[2][10], sh_Si[2][4], sh_nu[2][2];
+    __shared__ double sh_K1B[5][2], sh_G1B[2][5]; // K1 / G1 at the five indices of landmark 2
+    __shared__ int sh_two;
+
+    const int r = 2 * (blockIdx.x * 256 + tid);
+    const double* st = pv.state + (size_t)b * ld;
+    double* so = state_out + (size_t)b * ld;
+    double* Ub = pend.U + (size_t)b * pend.cap * ld;
+    double* Vb = pend.V + (size_t)b * pend.cap * ld;
+    const double2_t zero2 = {0.0, 0.0};
+
+    const size_t slot = (size_t)b * src.vmax + src.v;
+    int lm1 = src.lm_idx[slot], lm2 = src.v + 1 < src.vmax ? src.lm_idx[slot + 1] : -1;
+    if (lm1 >= pv.n) lm1 = -1;
+    if (lm1 < 0 || lm2 >= pv.n) lm2 = -1;
+    if (lm1 < 0) {  // nothing to correct: carry the state over, append two zero pairs
+        if (r < ld) {
+            *reinterpret_cast<double2_t*>(so + r) = *reinterpret_cast<const double2_t*>(st + r);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                *reinterpret_cast<double2_t*>(Ub + (size_t)(rc + q) * ld + r) = zero2;
+                *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + q) * ld + r) = zero2;
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) pv.rec[b].active = 0;
+        return;
+    }
+    const bool two_corr = lm2 >= 0;
+    const int lmB = two_corr ? lm2 : lm1;   // (a valid landmark for the address arithmetic of the second half)
+    auto cidx = [&](int k) { return k < 3 ? k : k < 5 ? 3 + 2 * lm1 + (k - 3) : 3 + 2 * lmB + (k - 5); };   // C[0..6]
+    // position of c5(lm1)[k] / c5(lm2)[k] inside C
+    auto posA = [](int k) { return k; };
+    auto posB = [](int k) { return k < 3 ? k : k + 2; };
+
+    const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    for (int idx = tid; idx < 7 * rc; idx += 256) {
+        const int k = idx / rc, j = idx - k * rc;
+        const int c = cidx(k);
+        sh_U7[k * kMaxPending + j] = Ub[(size_t)j * ld + c];
+        sh_V7[k * kMaxPending + j] = Vb[(size_t)j * ld + c];
+    }
+    __syncthreads();
+    if (tid < 49) {
+        const int k = tid / 7, l = tid % 7;
+        double v = Sg[(size_t)cidx(k) * ld + cidx(l)];
+        for (int j = 0; j < rc; j += 2)
+            v = __builtin_fma(-sh_U7[k * kMaxPending + j + 1], sh_V7[l * kMaxPending + j + 1],
+                              __builtin_fma(-sh_U7[k * kMaxPending + j], sh_V7[l * kMaxPending + j], v));
+        sh_C[k][l] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double* sn = pv.snap + (size_t)b * 4;
+        double theta, x, y;
+        if (src.fresh_pose) { theta = st[0]; x = st[1]; y = st[2]; }
+        else { theta = sn[0]; x = sn[1]; y = sn[2]; }
+        // ---- correction 1 on the core ----
+        MeasTerms m;
+        measurement_terms(st[2 * lm1 + 3], st[2 * lm1 + 4], src.z_xy[slot * 2], src.z_xy[slot * 2 + 1], theta, x, y, m);
+        double S55[5][5], S[2][2], Si[2][2];
+        for (int k = 0; k < 5; k++)
+            for (int l = 0; l < 5; l++) S55[k][l] = sh_C[posA(k)][posA(l)];
+        innovation_cov(S55, m.H, pv.p.r_meas, S);
+        inv2(S, Si);
+        for (int a = 0; a < 2; a++)
+            for (int k = 0; k < 5; k++) sh_H[0][a * 5 + k] = m.H[a][k];
+        sh_Si[0][0] = Si[0][0]; sh_Si[0][1] = Si[0][1]; sh_Si[0][2] = Si[1][0]; sh_Si[0][3] = Si[1][1];
+        const double nu0 = m.z0 - m.zh0, nu1 = normalize_angle(m.z1 - m.zh1);   // :182-183
+        sh_nu[0][0] = nu0; sh_nu[0][1] = nu1;
+        sh_two = two_corr ? 1 : 0;
+        if (two_corr) {
+            // K1, G1 on the 7 core indices (the arithmetic of the lanes below, on core entries)
+            double K1[7][2], G1[2][7];
+            for (int i = 0; i < 7; i++) {
+                double sht0 = 0.0, sht1 = 0.0, g0 = 0.0, g1 = 0.0;
+                for (int k = 0; k < 5; k++) {
+                    sht0 += sh_C[i][posA(k)] * m.H[0][k];
+                    sht1 += sh_C[i][posA(k)] * m.H[1][k];
+                    g0 += m.H[0][k] * sh_C[posA(k)][i];
+                    g1 += m.H[1][k] * sh_C[posA(k)][i];
+                }
+                K1[i][0] = sht0 * Si[0][0] + sht1 * Si[1][0];
+                K1[i][1] = sht0 * Si[0][1] + sht1 * Si[1][1];
+                G1[0][i] = g0; G1[1][i] = g1;
+            }
+            for (int k = 0; k < 5; k++) {
+                sh_K1B[k][0] = K1[posB(k)][0]; sh_K1B[k][1] = K1[posB(k)][1];
+                sh_G1B[0][k] = G1[0][posB(k)]; sh_G1B[1][k] = G1[1][posB(k)];
+            }
+            // landmark 2 after the first state update (:186); the pose of the call stays the stale one
+            const double t2x = st[2 * lm2 + 3] + (K1[5][0] * nu0 + K1[5][1] * nu1);
+            const double t2y = st[2 * lm2 + 4] + (K1[6][0] * nu0 + K1[6][1] * nu1);
+            MeasTerms m2;
+            measurement_terms(t2x, t2y, src.z_xy[(slot + 1) * 2], src.z_xy[(slot + 1) * 2 + 1], theta, x, y, m2);
+            for (int k = 0; k < 5; k++)
+                for (int l = 0; l < 5; l++)   // the block of landmark 2 after correction 1 (:191-192 on the core)
+                    S55[k][l] = sh_C[posB(k)][posB(l)] - (K1[posB(k)][0] * G1[0][posB(l)] + K1[posB(k)][1] * G1[1][posB(l)]);
+            innovation_cov(S55, m2.H, pv.p.r_meas, S);
+            inv2(S, Si);
+            for (int a = 0; a < 2; a++)
+                for (int k = 0; k < 5; k++) sh_H[1][a * 5 + k] = m2.H[a][k];
+            sh_Si[1][0] = Si[0][0]; sh_Si[1][1] = Si[0][1]; sh_Si[1][2] = Si[1][0]; sh_Si[1][3] = Si[1][1];
+            sh_nu[1][0] = m2.z0 - m2.zh0;
+            sh_nu[1][1] = normalize_angle(m2.z1 - m2.zh1);
+        }
+        if (blockIdx.x == 0) {
+            CorrRec rcd;
+            rcd.nu0 = two_corr ? sh_nu[1][0] : nu0; rcd.nu1 = two_corr ? sh_nu[1][1] : nu1;
+            rcd.active = 1; rcd.lm = two_corr ? lm2 : lm1; rcd.n_active = 0; rcd.pad = 0;
+            pv.rec[b] = rcd;
+            touch_landmark(pv, b, lm1);
+            if (two_corr) touch_landmark(pv, b, lm2);
+        }
+    }
+    __syncthreads();
+    if (r >= ld) return;
+
+    double2_t k1a = zero2, k1b = zero2, g1a = zero2, g1b = zero2, k2a = zero2, k2b = zero2, g2a = zero2, g2b = zero2;
+    double2_t snew = zero2;
+    if (r < N) {
+        const bool two = r + 1 < N;  // N is odd: the last lane owns one real index and one pad index
+        double2_t p[7], g[7];        // Sigma(r, C[k]) and Sigma(C[k], r) for r and r + 1
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const int c = cidx(k);
+            g[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)c * ld + r);
+            if (pend.symmetric) {
+                p[k] = g[k];
+                if (!two) p[k].y = 0.0;
+            } else {
+                p[k].x = Sg[(size_t)r * ld + c];
+                p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
+            }
+        }
+        auto ld4 = [&](int j, double2_t& a0, double2_t& a1, double2_t& b0, double2_t& b1) {
+            a0 = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
+            a1 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
+            b0 = *reinterpret_cast<const double2_t*>(Vb + (size_t)j * ld + r);
+            b1 = *reinterpret_cast<const double2_t*>(Vb + (size_t)(j + 1) * ld + r);
+        };
+        double2_t ua = zero2, ub = zero2, va = zero2, vb = zero2, ua1 = zero2, ub1 = zero2, va1 = zero2, vb1 = zero2;
+        if (rc > 0) { ld4(0, ua, ub, va, vb); ld4(2 < rc ? 2 : 0, ua1, ub1, va1, vb1); }
+        for (int j = 0; j < rc; j += 2) {
+            double2_t ua2, ub2, va2, vb2;
+            ld4(j + 4 < rc ? j + 4 : 0, ua2, ub2, va2, vb2);
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const double v5a = sh_V7[k * kMaxPending + j], v5b = sh_V7[k * kMaxPending + j + 1];
+                const double u5a = sh_U7[k * kMaxPending + j], u5b = sh_U7[k * kMaxPending + j + 1];
+                p[k].x = __builtin_fma(-ub.x, v5b, __builtin_fma(-ua.x, v5a, p[k].x));
+                p[k].y = __builtin_fma(-ub.y, v5b, __builtin_fma(-ua.y, v5a, p[k].y));
+                g[k].x = __builtin_fma(-u5b, vb.x, __builtin_fma(-u5a, va.x, g[k].x));
+                g[k].y = __builtin_fma(-u5b, vb.y, __builtin_fma(-u5a, va.y, g[k].y));
+            }
+            ua = ua1; ub = ub1; va = va1; vb = vb1;
+            ua1 = ua2; ub1 = ub2; va1 = va2; vb1 = vb2;
+        }
+        // ---- correction 1: K1 = (Sigma H1^T) S1^-1, G1 = H1 Sigma on the lane's indices (:178) ----
+        double2_t sht0 = zero2, sht1 = zero2;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            sht0.x += p[k].x * sh_H[0][k];     sht0.y += p[k].y * sh_H[0][k];
+            sht1.x += p[k].x * sh_H[0][5 + k]; sht1.y += p[k].y * sh_H[0][5 + k];
+            g1a.x += sh_H[0][k] * g[k].x;      g1a.y += sh_H[0][k] * g[k].y;
+            g1b.x += sh_H[0][5 + k] * g[k].x;  g1b.y += sh_H[0][5 + k] * g[k].y;
+        }
+        k1a.x = sht0.x * sh_Si[0][0] + sht1.x * sh_Si[0][2];
+        k1b.x = sht0.x * sh_Si[0][1] + sht1.x * sh_Si[0][3];
+        k1a.y = sht0.y * sh_Si[0][0] + sht1.y * sh_Si[0][2];
+        k1b.y = sht0.y * sh_Si[0][1] + sht1.y * sh_Si[0][3];
+        const double2_t sv = *reinterpret_cast<const double2_t*>(st + r);
+        snew.x = sv.x + (k1a.x * sh_nu[0][0] + k1b.x * sh_nu[0][1]);  // :186
+        snew.y = sv.y + (k1a.y * sh_nu[0][0] + k1b.y * sh_nu[0][1]);
+        if (r == 0) snew.x = normalize_angle(snew.x);                 // :187
+        if (sh_two) {
+            // ---- the lane's entries of landmark 2's rows / columns after correction 1 (:191-192), then correction 2 ----
+            sht0 = zero2; sht1 = zero2;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int q = k < 3 ? k : k + 2;   // position of c5(lm2)[k] in C
+                const double px = p[q].x - (k1a.x * sh_G1B[0][k] + k1b.x * sh_G1B[1][k]);
+                const double py = p[q].y - (k1a.y * sh_G1B[0][k] + k1b.y * sh_G1B[1][k]);
+                const double gx = g[q].x - (sh_K1B[k][0] * g1a.x + sh_K1B[k][1] * g1b.x);
+                const double gy = g[q].y - (sh_K1B[k][0] * g1a.y + sh_K1B[k][1] * g1b.y);
+                sht0.x += px * sh_H[1][k];     sht0.y += py * sh_H[1][k];
+                sht1.x += px * sh_H[1][5 + k]; sht1.y += py * sh_H[1][5 + k];
+                g2a.x += sh_H[1][k] * gx;      g2a.y += sh_H[1][k] * gy;
+                g2b.x += sh_H[1][5 + k] * gx;  g2b.y += sh_H[1][5 + k] * gy;
+            }
+            k2a.x = sht0.x * sh_Si[1][0] + sht1.x * sh_Si[1][2];
+            k2b.x = sht0.x * sh_Si[1][1] + sht1.x * sh_Si[1][3];
+            k2a.y = sht0.y * sh_Si[1][0] + sht1.y * sh_Si[1][2];
+            k2b.y = sht0.y * sh_Si[1][1] + sht1.y * sh_Si[1][3];
+            snew.x = snew.x + (k2a.x * sh_nu[1][0] + k2b.x * sh_nu[1][1]);
+            snew.y = snew.y + (k2a.y * sh_nu[1][0] + k2b.y * sh_nu[1][1]);
+            if (r == 0) snew.x = normalize_angle(snew.x);
+        }
+        if (!two) {  // pad stays 0
+            k1a.y = 0.0; k1b.y = 0.0; g1a.y = 0.0; g1b.y = 0.0; k2a.y = 0.0; k2b.y = 0.0; g2a.y = 0.0; g2b.y = 0.0; snew.y = 0.0;
+        }
+    }
+    *reinterpret_cast<double2_t*>(Ub + (size_t)rc * ld + r) = k1a;
+    *reinterpret_cast<double2_t*>(Ub + (size_t)(rc + 1) * ld + r) = k1b;
+    *reinterpret_cast<double2_t*>(Vb + (size_t)rc * ld + r) = g1a;
+    *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + 1) * ld + r) = g1b;
+    *reinterpret_cast<double2_t*>(Ub + (size_t)(rc + 2) * ld + r) = k2a;
+    *reinterpret_cast<double2_t*>(Ub + (size_t)(rc + 3) * ld + r) = k2b;
+    *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + 2) * ld + r) = g2a;
+    *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + 3) * ld + r) = g2b;
+    *reinterpret_cast<double2_t*>(so + r) = snew;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Flush: Sigma_base(r, c) -= sum over pending pairs (U[j](r) V[j](c) + U[j+1](r) V[j+1](c)).
 // Same streaming structure as k_rank2 (strip of 256 double2 columns, 16-row register groups, loads
 // before stores, non-temporal), with a loop over the pairs: U values are wave-uniform (scalar loads),
@@ -459,6 +692,11 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
 void launch_gain_delayed(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
                          hipStream_t s) {
     hipLaunchKernelGGL(k_gain_delayed, dim3((pv.ld / 2 + 255) / 256, pv.B), dim3(256), 0, s, pv, src, pend, state_out);
+}
+
+void launch_gain_delayed_pair(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(k_gain_delayed_pair, dim3((pv.ld / 2 + 255) / 256, pv.B), dim3(256), 0, s, pv, src, pend, state_out);
 }
 
 void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s) {

@@ -341,6 +341,10 @@ void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, 
 // corrected state to state_out (ping-pong) and appends the factor pair at rows pend.count, pend.count+1.
 void launch_gain_delayed(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
                          hipStream_t s);
+// Known-association log slots src.v and src.v + 1 (SRC_COMPACT_LOG) of every filter in ONE launch: the pending factor
+// rows are read once for both corrections; appends TWO pairs (rows pend.count .. pend.count + 3).
+void launch_gain_delayed_pair(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
+                              hipStream_t s);
 // Sigma_base -= sum_j U[j] V[j]^T for j < pend.count (count even); the caller then resets count to 0.
 void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s);
 // top of measurement(): pose snapshot (+ first-call landmark initialisation from init_xy [B][2n])

@@ -329,6 +329,15 @@ struct Pool {
 
     // one landmark correction, eager (gain + covariance stream) or delayed (gain only, factors appended).
     // active_N > 0: the correction is exactly confined to the leading active_N block (data_association()).
+    // delayed mode, known-association log slots src.v and src.v + 1 in one launch (the pending factors are read once for
+    // both corrections); the caller has made room for two pairs
+    int delayed_pair = 1;
+    ekf_status correct_pair(const ekf::CmdSrc& src) {
+        ekf::launch_gain_delayed_pair(pv, src, pending(), state_alt, stream);
+        std::swap(pv.state, state_alt);
+        pend_count += 4;
+        return EKF_OK;
+    }
     ekf_status correct(const ekf::CmdSrc& src, int active_N = 0) {
         if (pend_cap > 0 && (src.mode != ekf::SRC_ASSOC || pv.B == 1)) {
             // (a measurement that data_association() drops appends a zero pair: the state buffers swap either way)

@@ -336,6 +336,10 @@ ekf_status ekf_batch_mc_stats(ekf_batch_handle hb, int t, double out[6]);
  * rounding (measured asymmetry 1e-18 relative), so results still agree at 1e-9. */
 ekf_status ekf_set_update_mode(ekf_handle h, int max_pending_corrections, int symmetric_gather);
 ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections, int symmetric_gather);
+/* Delayed mode, ekf_batch_run_known: two consecutive log slots of a step (two landmarks of one measurement() call) are
+ * corrected by ONE launch that reads the pending factor rows once for both (enable != 0, default) instead of one launch
+ * per landmark.  Same results to rounding (the mode's tolerance, 1e-9 against the reference semantics). */
+ekf_status ekf_batch_set_delayed_pairing(ekf_batch_handle hb, int enable);
 
 /* ---- dense general-F covariance propagation, fp32 on the matrix cores (BASELINE.json configs[3]) ----
  * Sigma <- F * Sigma * F^T + Q for an ARBITRARY dense F: the reference's expression

@@ -198,3 +198,34 @@ def test_strip_form_flush_is_bit_identical_to_the_plain_flush(hip, B, n, k, vmax
             assert np.array_equal(res[0][0][b], res[other][0][b]), f"filter {b} state"
             assert np.array_equal(res[0][1][b], res[other][1][b]), f"filter {b} covariance"
     assert np.all(np.isfinite(res[0][1][0]))
+
+
+@pytest.mark.parametrize("k,vmax", [(32, 2), (7, 5), (3, 4), (2, 3), (1, 2), (16, 1)])
+def test_paired_delayed_gain_steps(hip, oracle, k, vmax):
+    """Delayed mode, two log slots per launch (k_gain_delayed_pair: the pending factor rows are read once for both
+    corrections; the second correction sees the first through the 7 x 7 core block every workgroup carries): against the
+    one-launch-per-landmark form at 1e-11, against the CPU checker at 1e-9 -- ragged visible counts (filters whose second
+    slot is empty, filters without any), odd slot counts (a trailing single launch), flush boundaries inside a step
+    (k = 3, 7), k too small for a pair (k = 1), and one landmark per step (never paired)."""
+    B, n, T = 6, 90, 14
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=600 + k + vmax, half_extent=2.5, min_spacing=0.2,
+                          max_visible_dis=1.0 if vmax > 1 else 1e9, vmax=vmax)
+    log = synth.make_known_log(cfg)
+    counts = (log.lm_idx >= 0).sum(axis=2)
+    if vmax > 1:
+        assert counts.min() < counts.max()
+    outs = []
+    for pairing in (True, False):
+        bt = hip.BatchEKF(B, n)
+        bt.set_update_mode(k)
+        bt.set_delayed_pairing(pairing)
+        bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+        bt.run_known(0, 5)
+        st = bt.run_known(5, T, time_kernels=True)
+        assert st["corrections"] == int(counts[5:].sum())
+        outs.append(([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)]))
+        bt.close()
+    ref_s, ref_c, _ = oracle.batch_run_known(log, oracle.STRUCTURED, want_cov=True, fast=False)
+    for b in range(B):
+        assert_parity(outs[0][0][b], outs[0][1][b], ref_s[b], ref_c[b], FP64_TOL, f"paired, filter {b} vs checker")
+        assert_parity(outs[0][0][b], outs[0][1][b], outs[1][0][b], outs[1][1][b], 1e-11, f"paired vs per landmark, filter {b}")
