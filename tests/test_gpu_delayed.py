@@ -229,3 +229,33 @@ def test_paired_delayed_gain_steps(hip, oracle, k, vmax):
     for b in range(B):
         assert_parity(outs[0][0][b], outs[0][1][b], ref_s[b], ref_c[b], FP64_TOL, f"paired, filter {b} vs checker")
         assert_parity(outs[0][0][b], outs[0][1][b], outs[1][0][b], outs[1][1][b], 1e-11, f"paired vs per landmark, filter {b}")
+
+
+def test_paired_delayed_gain_steps_random_shapes(hip, oracle):
+    """Seeded sweep over pool shapes for the paired gain step: map sizes around the 512-index workgroup slices (n = 254,
+    255, 256 -> N = 511, 513, 515), tiny maps (the 7 core indices overlap the whole state), visible counts 0 ... 6, every
+    k from 1 to 9 -- paired vs per landmark at 1e-11, and one filter per shape against the CPU checker at 1e-9."""
+    rng = np.random.default_rng(2718)
+    shapes = [(3, 2), (4, 3), (3, 254), (2, 255), (2, 256)] + [(int(rng.integers(1, 6)), int(rng.integers(4, 140))) for _ in range(7)]
+    for idx, (B, n) in enumerate(shapes):
+        k = 1 + idx % 9
+        vmax = int(rng.integers(1, 7))
+        T = 8
+        cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=9000 + idx, half_extent=2.5, min_spacing=0.05 if n > 100 else 0.2,
+                              max_visible_dis=float(rng.choice([0.8, 1.5, 1e9])), vmax=min(vmax, n))
+        log = synth.make_known_log(cfg)
+        outs = []
+        for pairing in (True, False):
+            bt = hip.BatchEKF(B, n)
+            bt.set_update_mode(k, symmetric_gather=bool(idx % 5 == 4))
+            bt.set_delayed_pairing(pairing)
+            bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+            bt.run_known(0, 3); bt.run_known(3, T)
+            outs.append(([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)]))
+            bt.close()
+        for b in range(B):
+            assert_parity(outs[0][0][b], outs[0][1][b], outs[1][0][b], outs[1][1][b], 1e-11, f"shape {idx} (B={B}, n={n}, k={k}) filter {b}")
+        o = oracle.OracleEKF(n, oracle.STRUCTURED)
+        for t in range(T):
+            o.prediction(*log.twist[t, 0]); o.measurement_compact(log.init_xy[0], log.lm_idx[t, 0], log.z_xy[t, 0])
+        assert_parity(outs[0][0][0], outs[0][1][0], o.state, o.cov, FP64_TOL, f"shape {idx} vs checker")
