@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const
 
 // ---------------------------------------------------------------------------------------------
 // Flush, second form (pools that fill the chip): a workgroup of 16 waves owns a strip of 256 columns for a row range.
-//   * The strip of all pending V rows (count x 2 KB, <= 128 KB) is read ONCE into LDS and shared by the waves: V
+//   * The strip of all pending V rows (count x 2 KB, <= 160 KB = 80 vectors) is read ONCE into LDS and shared by the waves: V
 //     costs no L2 bandwidth and no vector-memory wait in the FMA loop (k_flush: two L2 loads per pair and wave,
 //     waited for in the trip that issues them -- hipcc collapses the source's rotating prefetch).
 //   * A lane holds 8 rows x 4 columns (k_flush: 16 x 2): the same 64 accumulator registers, but a scalar operand
@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const
 // ---------------------------------------------------------------------------------------------
 constexpr int kStripWaves = 16;
 constexpr int kStripCols2 = 128;   // double2 columns per strip: lane l holds columns l and l + 64
+constexpr int kStripMaxVec = 80;   // pending vectors whose strip fits the 160 KB of LDS (2 KB each)
 
 // `col` = the lane's first column (base + c); its second column is 64 double2 (1 KB) further on: one address register
 // pair per row serves both.  live0 / live1: lanes past the last column of the matrix take no part.
@@ -653,16 +654,17 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
     if (g < ngroups) fl_load<NT>(a, col, row_begin + 8 * g, row_end - 1, ld2n, live0, live1);
 
     const double2_t zero2 = {0.0, 0.0};
-    {   // V strip -> LDS: wave w stages the vectors w, w + 16, w + 32, w + 48, all their loads in flight together
-        double2_t v[4][2];
+    {   // V strip -> LDS: wave w stages the vectors w, w + 16, ... (up to kStripMaxVec / 16 = 5), their loads in flight together
+        constexpr int kPerWave = kStripMaxVec / kStripWaves;
+        double2_t v[kPerWave][2];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < kPerWave; q++) {
             const int j = min(wave + kStripWaves * q, count - 1);
             v[q][0] = live0 ? Vb[(size_t)j * ld2n + cbase] : zero2;
             v[q][1] = live1 ? Vb[(size_t)j * ld2n + cbase + 64] : zero2;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < kPerWave; q++) {
             const int j = wave + kStripWaves * q;
             if (j < count) {
                 sh_V[j * kStripCols2 + lane] = v[q][0];
@@ -709,7 +711,7 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
     // staging once per range: 48.5 ms at 1024 rows, 52 at 512, 58 at 256), the plain form's does (41.5 ms up to 32
     // vectors = the stream floor, 58.9 ms at 64: tools/flush_sweep.py) -- the strip form takes over beyond 40.
     const bool forced = t.rows_per_block == -2;   // (tests: the strip form on pools of any size, any count <= 64)
-    if ((forced || (t.rows_per_block == 0 && pv.N >= 256 && pend.count > 40)) && pend.count <= 64) {
+    if ((forced || (t.rows_per_block == 0 && pv.N >= 256 && pend.count > 40)) && pend.count <= kStripMaxVec) {
         const int strips = (pv.ld / 2 + kStripCols2 - 1) / kStripCols2;
         int row_blocks = 1;
         while ((long long)pv.B * strips * row_blocks < 1024 && pv.N / (row_blocks * 2) >= 512) row_blocks *= 2;
@@ -719,9 +721,9 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (attr_state[dev] == 0)
             attr_state[dev] = (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kStripCols2 * 16) == hipSuccess &&
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kStripMaxVec * kStripCols2 * 16) == hipSuccess &&
                                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<false>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kStripCols2 * 16) == hipSuccess)
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kStripMaxVec * kStripCols2 * 16) == hipSuccess)
                                   ? 1 : 2;
         const bool attr_ok = attr_state[dev] == 1;
         if (attr_ok && (forced || (long long)pv.B * strips * row_blocks >= 512)) {

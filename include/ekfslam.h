@@ -253,7 +253,7 @@ ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]);
 /* Tuning knobs of the covariance rank-2 kernel: rows per workgroup, non-temporal access (0/1),
  * rows per load/store group (2, 4 or 8).  0 (nontemporal: < 0) restores the automatic choice; rows_per_block -1
  * keeps to the plain kernels (no row packing, no strip-form flush), -2 takes the strip-form flush of the delayed
- * update on pools of any size (count <= 64).  Results do not depend on them, bit for bit. */
+ * update on pools of any size (up to 80 pending vectors).  Results do not depend on them, bit for bit. */
 ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal, int group_rows);
 /* Report hook: the instantiation ekf::k_rank2<group_rows, nontemporal, threads> and the rows per workgroup that a
  * full-width eager correction of this pool launches (bench.py ties its PMC traffic record to this name). */

@@ -6,11 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ekf_slam_ml_amd import capi, synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-K, W = 64, 2
+K, W = 120, 2
 cfg = synth.config5(filters=B, steps=1 + W + K, n=1000)
 bt = capi.BatchEKF(B, 1000)
 bt.simulate_known_log(cfg, synth.make_world(1000, cfg.half_extent, cfg.min_spacing, cfg.world_seed))
-for k in (8, 16, 32, 64):
+KS = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [8, 16, 32, 64]
+for k in KS:
     for pair in (1, 0):
         for sym in (0, 1):
             bt.reset(); bt.set_update_mode(k, bool(sym)); bt.set_delayed_pairing(bool(pair))
