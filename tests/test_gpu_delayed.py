@@ -173,7 +173,7 @@ def test_delayed_data_association_without_flush(hip, oracle, k):
     f.close()
 
 
-@pytest.mark.parametrize("B,n,k,vmax", [(3, 130, 5, 3), (9, 500, 16, 2), (4, 1000, 8, 4), (2, 333, 3, 1), (5, 61, 32, 1)])
+@pytest.mark.parametrize("B,n,k,vmax", [(3, 130, 5, 3), (9, 500, 16, 2), (4, 1000, 8, 4), (2, 333, 3, 1), (5, 61, 32, 1), (3, 300, 40, 2), (2, 200, 37, 1)])
 def test_strip_form_flush_is_bit_identical_to_the_plain_flush(hip, B, n, k, vmax):
     """k_flush_strip (pools that fill the chip: V strip in LDS, 8 rows x 4 columns per lane, 4-vector scalar batches)
     applies the pending pairs to every element in the same order with the same fused multiply-adds as k_flush: forced
