@@ -213,7 +213,6 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     __shared__ double sh_C[7][8];                 // core block Sigma[C, C] as it stands before the call's corrections
     __shared__ double sh_H[2][10], sh_Si[2][4], sh_nu[2][2];
     __shared__ double sh_K1B[5][2], sh_G1B[2][5]; // K1 / G1 at the five indices of landmark 2
-    __shared__ int sh_two;
 
     const int r = 2 * (blockIdx.x * 256 + tid);
     const double* st = pv.state + (size_t)b * ld;
@@ -280,7 +279,6 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
         sh_Si[0][0] = Si[0][0]; sh_Si[0][1] = Si[0][1]; sh_Si[0][2] = Si[1][0]; sh_Si[0][3] = Si[1][1];
         const double nu0 = m.z0 - m.zh0, nu1 = normalize_angle(m.z1 - m.zh1);   // :182-183
         sh_nu[0][0] = nu0; sh_nu[0][1] = nu1;
-        sh_two = two_corr ? 1 : 0;
         if (two_corr) {
             // K1, G1 on the 7 core indices (the arithmetic of the lanes below, on core entries)
             double K1[7][2], G1[2][7];
@@ -385,7 +383,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
         snew.x = sv.x + (k1a.x * sh_nu[0][0] + k1b.x * sh_nu[0][1]);  // :186
         snew.y = sv.y + (k1a.y * sh_nu[0][0] + k1b.y * sh_nu[0][1]);
         if (r == 0) snew.x = normalize_angle(snew.x);                 // :187
-        if (sh_two) {
+        if (two_corr) {
             // ---- the lane's entries of landmark 2's rows / columns after correction 1 (:191-192), then correction 2 ----
             sht0 = zero2; sht1 = zero2;
 #pragma unroll
