@@ -26,7 +26,7 @@ constexpr int kAssocSlice = 256;
 // Scores of one reading against the M known landmarks: ONE LANDMARK PER THREAD, 64-thread workgroups spread over the
 // chip (the per-landmark chain -- two atan2, the divisions of H, S, S^-1 -- is ~800 instructions; M = 1000 takes two
 // rounds on 8 redundant workgroups but one round on 16 workgroups of 64).  Leaves score and correction terms per landmark.
-__global__ __launch_bounds__(64) void k_assoc_score(PoolView pv, const double* __restrict__ meas_j,
+__global__ __launch_bounds__(64) void k_assoc_score(PoolView pv, double mx, double my,
                                                     const AssocRec* __restrict__ assoc_in, double* __restrict__ scores,
                                                     double* __restrict__ terms, const double* __restrict__ Ub,
                                                     const double* __restrict__ Vb, int pc) {
@@ -36,7 +36,6 @@ __global__ __launch_bounds__(64) void k_assoc_score(PoolView pv, const double* _
     const double* __restrict__ st = pv.state;
     const int M = assoc_in[0].known_count;
     if (i >= M || i >= pv.n) return;
-    const double mx = meas_j[0], my = meas_j[1];
     MeasTerms m;
     measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, st[0], st[1], st[2], m);   // fresh pose, :219-221
     double S55[5][5], S[2][2], Si[2][2];
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(64) void k_assoc_score(PoolView pv, const double* _
     tr[14] = v0; tr[15] = v1;
 }
 
-__global__ __launch_bounds__(kAssocThreads) void k_assoc_meas(PoolView pv, const double* __restrict__ meas_j,
+__global__ __launch_bounds__(kAssocThreads) void k_assoc_meas(PoolView pv, double mx, double my,
                                                               const AssocRec* __restrict__ assoc_in,
                                                               AssocRec* __restrict__ assoc_next, int* __restrict__ assoc_out_j,
                                                               double* __restrict__ state_out, double* __restrict__ Uall,
@@ -102,7 +101,6 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_meas(PoolView pv, const
     __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
     __shared__ double sh_K5[kCallV][5][2], sh_G5[kCallV][5][2];   // pending pairs at {0,1,2} and at the winner's two indices
 
-    const double mx = meas_j[0], my = meas_j[1];
     const int M = assoc_in[0].known_count;
     const double theta = st[0], x = st[1], y = st[2];   // fresh pose, :219-221 / :331-333
     if (tid < 6 * pc) {   // pose part of the pending pairs
@@ -245,12 +243,12 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_meas(PoolView pv, const
     }
 }
 
-void launch_assoc_meas(const PoolView& pv, const double* meas_j, const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j,
+void launch_assoc_meas(const PoolView& pv, double mx, double my, const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j,
                        double* state_out, double* U, double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound,
                        double* scores, double* terms, hipStream_t s) {
     if (m_bound > 0)
-        hipLaunchKernelGGL(k_assoc_score, dim3((m_bound + 63) / 64), dim3(64), 0, s, pv, meas_j, assoc_in, scores, terms, U, V, pc);
-    hipLaunchKernelGGL(k_assoc_meas, dim3((pv.ld + kAssocSlice - 1) / kAssocSlice), dim3(kAssocThreads), 0, s, pv, meas_j, assoc_in,
+        hipLaunchKernelGGL(k_assoc_score, dim3((m_bound + 63) / 64), dim3(64), 0, s, pv, mx, my, assoc_in, scores, terms, U, V, pc);
+    hipLaunchKernelGGL(k_assoc_meas, dim3((pv.ld + kAssocSlice - 1) / kAssocSlice), dim3(kAssocThreads), 0, s, pv, mx, my, assoc_in,
                        assoc_next, assoc_out_j, state_out, U, V, cnt_out, pc, Nb, zero_upto, scores, terms);
 }
 

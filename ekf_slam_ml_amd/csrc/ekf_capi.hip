@@ -344,7 +344,6 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     // launch is cheap and two launches per reading win (configs[2]'s discovery run: 12.7 k vs 10.5 k steps/s).
     if (!delayed && P.pv.B == 1 && P.call_fused_ok() && active_dim(0) >= 1400) {
         EKFC(P.ensure_callfused());
-        EKFC(need_dev());
         if (!P.terms) EKFC(P.dalloc(&P.terms, (size_t)(n > 0 ? n : 1) * 16));
         P.alt_synced = false;
         for (int j0 = 0; j0 < J; j0 += ekf::kCallV) {
@@ -352,7 +351,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
             for (int jj = 0; jj < jc; jj++) {
                 const int j = j0 + jj;
                 EKFC(P.prof_begin(1));
-                ekf::launch_assoc_meas(P.pv, P.meas_dev + 2 * (size_t)j, P.pv.assoc, P.assoc_alt, P.assoc_out_dev + j, P.cf_state,
+                ekf::launch_assoc_meas(P.pv, meas_xy[2 * j], meas_xy[2 * j + 1], P.pv.assoc, P.assoc_alt, P.assoc_out_dev + j, P.cf_state,
                                        P.cf_U, P.cf_V, P.cf_cnt, jj, active_dim(j), jj == jc - 1 ? ekf::rank2v_round_count(jc) : 0,
                                        known_count + j < n ? known_count + j : n, P.scores, P.terms, P.stream);
                 EKFC(P.prof_end());

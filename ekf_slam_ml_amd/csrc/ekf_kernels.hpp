@@ -447,10 +447,11 @@ void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, doub
 void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, int vcount, const Rank2Tuning& t,
                    hipStream_t s, const double* pred = nullptr);
 
-// data_association() of a single filter with Sigma streamed once per call (ekf_assocfused.hip): one reading = one launch
+// data_association() of a single filter with Sigma streamed once per call (ekf_assocfused.hip; the reading (mx, my) travels
+// by value): one reading = one launch
 // (scores against the stored covariance minus the call's pc pending pairs, decision, gain -> pair pc, state out of
 // place); the caller ends the call with launch_rank2v.  Nb: active dimension of the reading (discovered prefix).
-void launch_assoc_meas(const PoolView& pv, const double* meas_j, const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j,
+void launch_assoc_meas(const PoolView& pv, double mx, double my, const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j,
                        double* state_out, double* U, double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound,
                        double* scores, double* terms, hipStream_t s);
 int rank2v_round_count(int vcount);   // corrections per pass, rounded up to an instantiated count of k_rank2v
