@@ -46,6 +46,17 @@ def test_two_ranks_through_torchrun_aggregate_like_one():
     work_b = b["value"] * b["ms_per_step"] * b["steps"]
     assert abs(work_b / work_a - 2.0) < 1e-9
     assert b["metric"] == a["metric"] and b["unit"] == a["unit"] and b["steps"] == 3 and b["warmup"] == 1
+    # the driver's contract keys, on both lines
+    for d in (a, b):
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in d, key
+        assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64" and "workload" in d["config"]
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        assert "traffic" in r and r["achieved"] > 0
+        # value = whole-job corrections / max-over-ranks time: consistent with ms_per_step
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (d["n_gpus"] * 96 * 2) - 1.0) < 1e-9
 
 
 def test_launcher_rank_count_mismatch_is_refused():
