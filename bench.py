@@ -15,6 +15,9 @@ The same JSON line carries, as separately reported sub-objects (never mixed into
   configs_1 (single filter n = 200 known, through the C ABI), configs_2 (single filter n = 1000 unknown),
   configs_3 (dense F Sigma F^T + Q, N = 10003, fp32 MFMA).
 
+At N > 1 only the contract leg and the delayed leg run (an 8-rank job is ~20 s); the line then also carries the
+per-rank spread of the timed region (rank_ms_per_step_min / _max) next to the MAX-reduced ms_per_step.
+
   python bench.py [--gpus N] [--steps K] [--warmup W] [--filters B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 (`python bench.py --gpus N` with N > 1 outside torchrun starts that launcher as a child process itself.)
@@ -42,6 +45,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--filters", type=int, default=0, help="filters per GPU (0 = 4096, reduced to fit HBM)")
+    ap.add_argument("--total-filters", type=int, default=0,
+                    help="filters of the whole job, sharded over the ranks by global id (blocks may differ by one "
+                         "filter); 0 = --filters per GPU (weak scaling)")
     ap.add_argument("--landmarks", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-filters", type=int, default=0)
@@ -144,15 +150,25 @@ def leg_configs_1(device, cores, steps=2000, warm=100, want_cpu=True):
            "value": corr / dt, "unit": "update steps/s (landmark corrections)", "filter_steps_per_s": (steps - warm) / dt,
            "corrections_per_step": corr / (steps - warm), "us_per_correction": dt / corr * 1e6}
     kern_us = prof["stream_ms"] / max(prof["stream_launches"], 1) * 1e3
+    # Two figures, never mixed: `contract` prices every correction at the eager stream's
+    # 16 N^2 bytes; `streamed` counts the bytes the launches of this path really move -- one pass over Sigma per CALL
+    # (16 N^2 per k_rank2v launch) plus the factor kernel's two panels (2 x (3 + 2V) rows / columns of 8 N bytes) and the
+    # factor rows it writes and the pass re-reads (4 rows x 8 N bytes x 2 per correction).
+    launches = max(prof["stream_launches"], 1)
+    streamed_bytes = launches * 16.0 * N * N + (steps - warm) * 2 * 3 * 8.0 * N + corr * (2 * 2 * 8.0 * N + 2 * 4 * 8.0 * N)
     out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                       "achieved": corr / dt * bytes_corr / 1e9, "frac": corr / dt * bytes_corr / 1e9 / HBM_PEAK_GBS,
+                       "achieved": streamed_bytes / dt / 1e9, "frac": streamed_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                       "streamed_frac": streamed_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                       "contract_GBps": corr / dt * bytes_corr / 1e9, "contract_frac": corr / dt * bytes_corr / 1e9 / HBM_PEAK_GBS,
                        "traffic": None, "algorithmic_bytes_per_correction": bytes_corr,
+                       "streamed_bytes_per_correction": streamed_bytes / corr,
                        "kernel_avg_us": kern_us, "kernel_launches": prof["stream_launches"],
-                       "corrections_per_launch": corr / max(prof["stream_launches"], 1),
-                       "in_kernel_GBps": bytes_corr * corr / max(prof["stream_launches"], 1) / (kern_us * 1e-6) / 1e9,
-                       "note": "Sigma = 1.3 MB lives in L2: latency-bound, not bandwidth-bound; `achieved` is end to "
-                               "end (corrections/s x 16 N^2 B), kernel_avg_us from HIP events around every "
-                               "covariance-streaming launch in a second, instrumented pass"}
+                       "corrections_per_launch": corr / launches,
+                       "in_kernel_GBps": bytes_corr / (kern_us * 1e-6) / 1e9,
+                       "note": "latency-bound, not bandwidth-bound (Sigma = 1.3 MB lives in L2): `achieved` / `frac` = bytes "
+                               "the launches really move / wall time; contract_* = corrections/s x 16 N^2 B (the eager "
+                               "stream's price per correction, which this path does not pay); in_kernel_GBps = 16 N^2 B of "
+                               "one pass / its HIP-event time (a second, instrumented pass)"}
     if want_cpu:
         from oracle import binding as ob  # checker / baseline only
         o = ob.OracleEKF(n, ob.STRUCTURED, fast=True)
@@ -272,12 +288,19 @@ def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
                        "known_landmarks": n, "measurements": nm, "corrections": nc, "steps": full_steps,
                        "score_kernel_avg_us": s_us, "score_launches": prof["score_launches"],
                        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                                    "achieved": nc / dt * bytes_corr / 1e9, "frac": nc / dt * bytes_corr / 1e9 / HBM_PEAK_GBS,
+                                    "achieved": prof["stream_launches"] * bytes_corr / dt / 1e9,
+                                    "frac": prof["stream_launches"] * bytes_corr / dt / 1e9 / HBM_PEAK_GBS,
+                                    "streamed_frac": prof["stream_launches"] * bytes_corr / dt / 1e9 / HBM_PEAK_GBS,
+                                    "contract_GBps": nc / dt * bytes_corr / 1e9,
+                                    "contract_frac": nc / dt * bytes_corr / 1e9 / HBM_PEAK_GBS,
                                     "traffic": None, "algorithmic_bytes_per_correction": bytes_corr,
                                     "kernel_avg_us": k_us, "kernel_launches": prof["stream_launches"],
+                                    "corrections_per_launch": nc / max(prof["stream_launches"], 1),
                                     "in_kernel_GBps": bytes_corr / (k_us * 1e-6) / 1e9,
-                                    "note": "one decision + full-width correction launch per measurement; Sigma = 32 MB "
-                                            "is served by the Infinity Cache between launches; `achieved` is end to end"}}
+                                    "note": "one launch per reading (decision + gain against the stored covariance minus the "
+                                            "call's pending pairs) and ONE pass over Sigma per call: `achieved` / `frac` = "
+                                            "passes x 16 N^2 B / wall time (what the launches move); contract_* = "
+                                            "corrections/s x 16 N^2 B; Sigma = 32 MB is served by the Infinity Cache"}}
     if want_cpu:
         from oracle import binding as ob  # checker / baseline only
         o = ob.OracleEKF(n, ob.STRUCTURED, fast=True)
@@ -416,11 +439,19 @@ def main():
     T = W + max(K, Kd) + 1  # step 0 = first measurement() call (landmark initialisation, no corrections)
 
     from ekf_slam_ml_amd import shard
-    first_id, count = shard.shard(B * world, world, rank)  # weak scaling: B filters per GPU, global ids
-    assert count == B
+    # weak scaling: B filters per GPU, contiguous blocks of global ids; --total-filters shards a fixed job instead
+    # (blocks then differ by at most one filter)
+    first_id, count = shard.shard(a.total_filters if a.total_filters > 0 else B * world, world, rank)
+    if count > B or count < 1:
+        raise SystemExit(f"bench.py: rank {rank}'s share of {count} filters does not fit ({B} per GPU)")
+    B = count
     cfg = synth.config5(filters=B, steps=T, first_filter_id=first_id, n=n)
     bt = capi.BatchEKF(B, n, device=local)
     bt.set_tuning(a.rows, a.nt)
+    # The contract leg is the EAGER per-landmark stream: every correction streams Sigma once (16 N^2 B, SURVEY.md
+    # section 8(d)).  The library's default for pools is the exact call-fused pass (one stream per call), which is
+    # reported separately below -- so the default is switched off here, explicitly.
+    bt.set_call_fused(False)
     if a.host_log:
         log = synth.make_known_log(cfg)
         bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
@@ -447,9 +478,15 @@ def main():
 
     corr = float(st["corrections"])
     fsteps = float(st["filter_steps"])
-    # the only collective of the job: RCCL all-reduce of a few scalars (max wall, summed work, ranks seen)
+    # the only collectives of the job: RCCL all-reduces of a few scalars (max / min wall, summed work, ranks seen)
+    wall_min, wall_max = shard.wall_spread(wall, device=red_dev)
     wall, corr, fsteps = shard.reduce_throughput(wall, corr, fsteps, device=red_dev)
     ranks_seen = shard.count_ranks(device=red_dev)
+    # Monte-Carlo consistency of the batch against the simulated ground truth (f4), at the step the pool stands at
+    # NOW: the last step it ran is W + K (step 0 = the initialising call)
+    mc_main = bt.mc_stats(W + K) if (rank == 0 and not a.host_log) else None
+    if world > 1:   # an N-rank job runs the contract leg and the delayed leg only
+        a.no_active_set = a.no_unknown = a.no_small = a.no_configs = a.no_call_fused = True
     cores = int(os.environ.get("EKF_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
     want_cpu = world == 1 and not a.no_cpu_baseline
     # the eager leg's own end states: the CPU baseline's parity spot-check and the other legs compare against THESE
@@ -494,9 +531,46 @@ def main():
                        "note": "Sigma = Sigma_base - sum K_j (H Sigma)_j kept as factors, rewritten once per "
                                "k corrections; the two corrections of a step share one gain launch; results equal the "
                                "eager path to rounding (tests/test_gpu_delayed.py)"}
-            if Kd == K:
-                dstate = np.stack([bt.state(b) for b in range(min(B, 4))])
-                delayed["max_abs_state_diff_vs_eager"] = float(np.abs(dstate - eager_state[:len(dstate)]).max())
+            # Parity of THIS configuration (n, k, pairs, automatic flush form) at the step it stands at, W + Kd: the first
+            # filters of the pool (same global ids -> same inputs) re-run eagerly on a side pool, and on the CPU port.
+            nref = min(B, 4)
+            dstate = np.stack([bt.state(b) for b in range(nref)])
+            dcov = bt.cov(0)
+            import copy
+            cfg_r = copy.copy(cfg)
+            cfg_r.filters = nref
+            ref = capi.BatchEKF(nref, n, device=local)
+            ref.set_call_fused(False)
+            if a.host_log:
+                ref.upload_known_log(log.twist[:, :nref], log.lm_idx[:, :nref], log.z_xy[:, :nref], log.init_xy[:nref])
+            else:
+                ref.simulate_known_log(cfg_r, world_xy)
+            ref.run_known(0, 1 + W + Kd)
+            rstate = np.stack([ref.state(b) for b in range(nref)])
+            rcov = ref.cov(0)
+            delayed["parity_filters"] = nref
+            delayed["parity_step"] = W + Kd
+            delayed["max_abs_state_diff_vs_eager"] = float(np.abs(dstate - rstate).max())
+            delayed["max_rel_cov_diff_vs_eager"] = float(np.abs(dcov - rcov).max() / np.abs(rcov).max())
+            fcn = bt.form_counts()
+            delayed["flush_form"] = "strip (k_flush_strip)" if fcn["flush_strip"] else "plain (k_flush)"
+            delayed["gain_launches_paired"] = fcn["gain_pairs"]
+            if want_cpu:
+                from oracle import binding as ob  # checker only
+                if a.host_log:
+                    subr = synth.KnownLog(cfg_r, log.world, log.twist[:, :nref], log.lm_idx[:, :nref], log.z_xy[:, :nref],
+                                          log.init_xy[:nref])
+                else:
+                    tw, li, zz, ii, _ = ref.download_log(want_truth=False)
+                    subr = synth.KnownLog(cfg_r, world_xy, tw, li, zz, ii)
+                cfg_r2 = copy.copy(cfg_r)
+                cfg_r2.steps = 1 + W + Kd
+                subr = synth.KnownLog(cfg_r2, subr.world, subr.twist[:1 + W + Kd], subr.lm_idx[:1 + W + Kd],
+                                      subr.z_xy[:1 + W + Kd], subr.init_xy)
+                cst, ccv, _ = ob.batch_run_known(subr, ob.STRUCTURED, nthreads=min(cores, nref), want_cov=True, fast=False)
+                delayed["max_abs_state_diff_vs_cpu_port"] = float(np.abs(dstate - cst).max())
+                delayed["max_rel_cov_diff_vs_cpu_port"] = float(np.abs(dcov - ccv[0]).max() / np.abs(ccv[0]).max())
+            ref.close()
         bt.set_update_mode(0)
 
     # Separately reported leg: the SAME steps with every measurement() call fused (ekf_callfused.hip) -- the gains and
@@ -580,11 +654,12 @@ def main():
             "unit": "update steps/s (1 update step = 1 landmark correction: gain + state + covariance)",
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall / K * 1e3,
+            "rank_ms_per_step_min": wall_min / K * 1e3, "rank_ms_per_step_max": wall_max / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[4], one GPU's share: {B} independent EKF_SLAM filters per "
                                    f"GPU, n={n} landmarks (N={N}), known association, V=2 corrections per filter step",
-                       "filters_per_gpu": B, "landmarks": n, "state_dim": N, "corrections_per_filter_step": 2,
+                       "filters_per_gpu": B, "filters_total": int(round(fsteps / K)), "landmarks": n, "state_dim": N, "corrections_per_filter_step": 2,
                        "filter_steps_per_s": fsteps / wall, "sharding": f"independent filters x {world} GPUs",
                        "ranks_seen": ranks_seen, "hbm_bytes_per_gpu": bt.device_bytes()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -603,9 +678,8 @@ def main():
             out["call_fused_update"] = callf
         if active is not None:
             out["active_set_update"] = active
-        if not a.host_log:
-            # Monte-Carlo consistency of the batch against the simulated ground truth (f4)
-            out["mc_consistency"] = bt.mc_stats(T - 1)
+        if mc_main is not None:
+            out["mc_consistency"] = dict(mc_main, step=W + K)
         if want_cpu:
             # bounded sample: ~10 s of CPU work incl. the untimed warm-up (each filter is 32 MB of covariance: 82 GB)
             import copy

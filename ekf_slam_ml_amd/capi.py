@@ -30,11 +30,11 @@ SYMBOLS = [
     "ekf_last_error", "ekf_default_params", "ekf_device_count",
     "ekf_create", "ekf_destroy", "ekf_clone", "ekf_predict", "ekf_measure_known", "ekf_associate",
     "ekf_maha_scores", "ekf_get_pose", "ekf_get_landmarks", "ekf_dim", "ekf_get_state", "ekf_set_state",
-    "ekf_get_cov", "ekf_set_cov", "ekf_get_init_flag", "ekf_set_init_flag", "ekf_sync", "ekf_set_tuning", "ekf_set_active_prefix", "ekf_set_small_map_path", "ekf_set_active_set", "ekf_batch_set_active_set", "ekf_batch_get_touched",
+    "ekf_get_cov", "ekf_set_cov", "ekf_get_init_flag", "ekf_set_init_flag", "ekf_sync", "ekf_set_tuning", "ekf_set_active_set", "ekf_batch_set_active_set", "ekf_batch_get_touched",
     "ekf_batch_create", "ekf_batch_destroy", "ekf_batch_reset", "ekf_batch_device_bytes",
     "ekf_batch_upload_known_log", "ekf_batch_run_known", "ekf_batch_upload_unknown_log", "ekf_batch_run_unknown",
-    "ekf_batch_get_known_counts", "ekf_batch_get_decisions", "ekf_batch_set_active_prefix", "ekf_batch_set_small_map_path", "ekf_set_fused_correction", "ekf_batch_get_state", "ekf_batch_get_cov",
-    "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning", "ekf_batch_set_delayed_pairing",
+    "ekf_batch_get_known_counts", "ekf_batch_get_decisions", "ekf_batch_get_state", "ekf_batch_get_cov",
+    "ekf_batch_get_poses", "ekf_batch_checksum", "ekf_batch_set_tuning",
     "ekf_set_update_mode", "ekf_batch_set_update_mode",
     "ekf_default_sim_params", "ekf_batch_simulate_known_log", "ekf_batch_download_log", "ekf_batch_mc_stats",
     "ekf_circle_fit_scans", "ekf_normalize_angles",
@@ -42,9 +42,15 @@ SYMBOLS = [
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
     "ekf_dense_launch_info", "ekf_batch_rank2_variant",
     "ekf_set_profiling", "ekf_get_profile", "ekf_batch_set_known_counts",
-    "ekf_set_cooperative_tick", "ekf_cooperative_trace", "ekf_set_call_fused", "ekf_batch_set_call_fused",
-    "ekf_batch_set_step_fused",
+    "ekf_set_forms", "ekf_get_forms", "ekf_batch_set_forms", "ekf_batch_get_forms", "ekf_batch_form_counts",
+    "ekf_phase_trace",
 ]
+
+# ekf_form (include/ekfslam.h): launch structures the library may take where they apply; all exact forms are bit-identical
+FORM_SMALL_MAP, FORM_FUSED_CORRECTION, FORM_CALL_FUSED, FORM_ACTIVE_PREFIX = 1 << 0, 1 << 1, 1 << 2, 1 << 3
+FORM_STEP_FUSED, FORM_STEP_SPLIT_PASS, FORM_DELAYED_PAIR, FORM_ROW_PACKING = 1 << 4, 1 << 5, 1 << 6, 1 << 7
+FORM_STRIP_FLUSH, FORM_STRIP_FLUSH_ALWAYS = 1 << 8, 1 << 9
+FORMS_DEFAULT = (1 << 9) - 1
 
 
 class EkfError(RuntimeError):
@@ -138,8 +144,6 @@ def load():
         "ekf_get_init_flag": [h, _ip],
         "ekf_set_init_flag": [h, C.c_int],
         "ekf_sync": [h],
-        "ekf_set_active_prefix": [h, C.c_int],
-        "ekf_set_small_map_path": [h, C.c_int],
         "ekf_set_active_set": [h, C.c_int],
         "ekf_batch_set_active_set": [h, C.c_int],
         "ekf_batch_get_touched": [h, _ip],
@@ -147,9 +151,6 @@ def load():
         "ekf_batch_run_unknown": [h, C.c_int, C.c_int, C.c_int, C.POINTER(RunStats)],
         "ekf_batch_get_known_counts": [h, _ip],
         "ekf_batch_get_decisions": [h, _ip],
-        "ekf_batch_set_active_prefix": [h, C.c_int],
-        "ekf_batch_set_small_map_path": [h, C.c_int],
-        "ekf_set_fused_correction": [h, C.c_int],
         "ekf_set_tuning": [h, C.c_int, C.c_int, C.c_int],
         "ekf_batch_create": [C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.POINTER(h)],
         "ekf_batch_destroy": [h],
@@ -162,7 +163,6 @@ def load():
         "ekf_batch_get_poses": [h, _dp],
         "ekf_batch_checksum": [h, _dp],
         "ekf_batch_set_tuning": [h, C.c_int, C.c_int, C.c_int],
-        "ekf_batch_set_delayed_pairing": [h, C.c_int],
         "ekf_set_update_mode": [h, C.c_int, C.c_int],
         "ekf_batch_set_update_mode": [h, C.c_int, C.c_int],
         "ekf_batch_simulate_known_log": [h, C.POINTER(SimParams), _dp, C.c_int, C.c_int],
@@ -183,11 +183,12 @@ def load():
         "ekf_batch_rank2_variant": [h, _ip, _ip, _ip, _ip],
         "ekf_batch_set_known_counts": [h, _ip],
         "ekf_set_profiling": [h, C.c_int],
-        "ekf_set_cooperative_tick": [h, C.c_int, C.c_int],
-        "ekf_set_call_fused": [h, C.c_int],
-        "ekf_batch_set_call_fused": [h, C.c_int],
-        "ekf_batch_set_step_fused": [h, C.c_int],
-        "ekf_cooperative_trace": [h, C.c_int, C.POINTER(C.c_longlong), _ip],
+        "ekf_set_forms": [h, C.c_uint],
+        "ekf_get_forms": [h, C.POINTER(C.c_uint)],
+        "ekf_batch_set_forms": [h, C.c_uint],
+        "ekf_batch_get_forms": [h, C.POINTER(C.c_uint)],
+        "ekf_batch_form_counts": [h, C.POINTER(C.c_longlong)],
+        "ekf_phase_trace": [h, C.c_int, C.POINTER(C.c_longlong)],
         "ekf_get_profile": [h, _dp, C.POINTER(C.c_longlong)],
     }
     for name, argtypes in sig.items():
@@ -336,33 +337,42 @@ class EKF_SLAM:
         """Stream only the rows of the touched set in the eager correction (exact; opt-in)."""
         _check(self._lib.ekf_set_active_set(self._h, int(bool(enable))))
 
+    @property
+    def forms(self):
+        f = C.c_uint()
+        _check(self._lib.ekf_get_forms(self._h, C.byref(f)))
+        return f.value
+
+    def set_forms(self, forms=FORMS_DEFAULT):
+        """which launch structures may be taken (FORM_* bits; test / measurement hook, results do not depend on it)"""
+        _check(self._lib.ekf_set_forms(self._h, int(forms)))
+
+    def _form(self, bit, enable):
+        self.set_forms(self.forms | bit if enable else self.forms & ~bit)
+
     def set_small_map_path(self, enable=True):
-        _check(self._lib.ekf_set_small_map_path(self._h, int(bool(enable))))
+        self._form(FORM_SMALL_MAP, enable)
 
     def set_active_prefix(self, enable=True):
-        _check(self._lib.ekf_set_active_prefix(self._h, int(bool(enable))))
+        self._form(FORM_ACTIVE_PREFIX, enable)
 
     def set_fused_correction(self, enable=True):
-        _check(self._lib.ekf_set_fused_correction(self._h, int(bool(enable))))
+        self._form(FORM_FUSED_CORRECTION, enable)
+
+    def set_call_fused(self, enable=True):
+        """measurement() as two launches per call (factor panels + one pass over Sigma); default on, bit-identical"""
+        self._form(FORM_CALL_FUSED, enable)
 
     def set_tuning(self, rows_per_block=0, nontemporal=-1, group_rows=0):
         _check(self._lib.ekf_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
 
-    def set_call_fused(self, enable=True):
-        """measurement() as two launches per call (factor panels + one pass over Sigma); default on, bit-identical"""
-        _check(self._lib.ekf_set_call_fused(self._h, int(bool(enable))))
-
-    def set_cooperative_tick(self, enable=True, workgroups=0):
-        """mid-size maps: prediction() + measurement() of a tick as ONE launch, Sigma resident in LDS (default on)"""
-        _check(self._lib.ekf_set_cooperative_tick(self._h, int(bool(enable)), int(workgroups)))
-
-    def cooperative_trace(self, enable=True, fetch=False):
-        """phase stamps (100 MHz ticks) of the last cooperative tick: array [workgroups, 64], or None"""
-        out = np.zeros((256, 64), dtype=np.int64)
-        g = C.c_int(0)
-        _check(self._lib.ekf_cooperative_trace(self._h, int(bool(enable)), out.ctypes.data_as(C.POINTER(C.c_longlong)) if fetch else None,
-                                               C.byref(g)))
-        return out[:g.value] if fetch else None
+    def phase_trace(self, enable=True, fetch=False):
+        """shader-clock stamps of the last two-launch measurement() call: array [2, 64] (row 0 the control wave, row 1
+        the first slice wave of workgroup 0), or None"""
+        out = np.zeros((2, 64), dtype=np.int64)
+        _check(self._lib.ekf_phase_trace(self._h, int(bool(enable)),
+                                         out.ctypes.data_as(C.POINTER(C.c_longlong)) if fetch else None))
+        return out if fetch else None
 
     def set_profiling(self, enable=True):
         """HIP-event timing of every covariance-streaming (class 0) and scoring (class 1) launch; resets the sums"""
@@ -506,11 +516,41 @@ class BatchEKF:
                                                int(time_kernels), C.byref(st)))
         return st.as_dict()
 
+    @property
+    def forms(self):
+        f = C.c_uint()
+        _check(self._lib.ekf_batch_get_forms(self._h, C.byref(f)))
+        return f.value
+
+    def set_forms(self, forms=FORMS_DEFAULT):
+        """which launch structures may be taken (FORM_* bits; test / measurement hook, results do not depend on it)"""
+        _check(self._lib.ekf_batch_set_forms(self._h, int(forms)))
+
+    def _form(self, bit, enable):
+        self.set_forms(self.forms | bit if enable else self.forms & ~bit)
+
+    def form_counts(self):
+        """covariance passes per form since creation: plain / strip flushes, paired delayed gain launches, call-fused
+        passes, per-landmark rank-2 streams, step-fused launches with a separate pass"""
+        c = (C.c_longlong * 6)()
+        _check(self._lib.ekf_batch_form_counts(self._h, c))
+        return dict(zip(("flush_plain", "flush_strip", "gain_pairs", "call_fused_passes", "rank2_streams", "step_split_passes"),
+                        (int(x) for x in c)))
+
     def set_active_prefix(self, enable=True):
-        _check(self._lib.ekf_batch_set_active_prefix(self._h, int(bool(enable))))
+        self._form(FORM_ACTIVE_PREFIX, enable)
 
     def set_small_map_path(self, enable=True):
-        _check(self._lib.ekf_batch_set_small_map_path(self._h, int(bool(enable))))
+        self._form(FORM_SMALL_MAP, enable)
+
+    def set_row_packing(self, enable=True):
+        """narrow maps: the row-packed rank-2 kernel (default) / the plain kernel"""
+        self._form(FORM_ROW_PACKING, enable)
+
+    def set_strip_flush(self, mode="auto"):
+        """delayed mode: "auto" (default: beyond 40 pending vectors on pools that fill the chip), "never", "always" """
+        f = self.forms & ~(FORM_STRIP_FLUSH | FORM_STRIP_FLUSH_ALWAYS)
+        self.set_forms(f | {"auto": FORM_STRIP_FLUSH, "never": 0, "always": FORM_STRIP_FLUSH | FORM_STRIP_FLUSH_ALWAYS}[mode])
 
     def set_known_counts(self, counts):
         """every filter's known_count (leading run of its known_list) -- the batch twin of the known_list argument"""
@@ -551,17 +591,20 @@ class BatchEKF:
         _check(self._lib.ekf_batch_set_tuning(self._h, rows_per_block, nontemporal, group_rows))
 
     def set_call_fused(self, enable=True):
-        """every measurement() call of the pool as factor panels + ONE pass over Sigma (exact; default off for pools)"""
-        _check(self._lib.ekf_batch_set_call_fused(self._h, int(bool(enable))))
+        """every measurement() call of the pool as factor panels + ONE pass over Sigma (exact; default on); off = the
+        eager per-landmark stream bench.py quotes `value` / `roofline` on"""
+        self._form(FORM_CALL_FUSED, enable)
 
     def set_delayed_pairing(self, enable=True):
         """delayed mode: two consecutive log slots of a step per launch (default) / one launch per landmark"""
-        _check(self._lib.ekf_batch_set_delayed_pairing(self._h, int(bool(enable))))
+        self._form(FORM_DELAYED_PAIR, enable)
 
     def set_step_fused(self, enable=True):
         """unknown association beyond the LDS-resident path: True / 1 = one launch per step, two for big prefixes
         (default); 2 = always one launch; False / 0 = four launches per measurement slot"""
-        _check(self._lib.ekf_batch_set_step_fused(self._h, int(enable)))
+        e = int(enable)
+        f = self.forms & ~(FORM_STEP_FUSED | FORM_STEP_SPLIT_PASS)
+        self.set_forms(f | (0 if e == 0 else FORM_STEP_FUSED | (FORM_STEP_SPLIT_PASS if e == 1 else 0)))
 
     def rank2_kernel(self):
         """name of the k_rank2 instantiation a full-width eager correction of this pool launches, + rows per workgroup"""

@@ -17,8 +17,9 @@
 //       x <- ((x - (K_0[r].G_0[c])) - (K_1[r].G_1[c])) - ...      -- the very sequence the per-landmark path applies.
 //
 // k_call_factors  grid (column/row slices of 256, filters).  Wave 0 of every workgroup runs the core filter (the
-//                 transcendental chain, lane-parallel: wave_terms) one correction AHEAD of the other waves, which carry
-//                 one panel column and one panel row per thread in registers and emit the factors U = K, Vf = G.
+//                 transcendental chain, lane-parallel: wave_terms) one correction AHEAD of the other waves (wave 1 updates the
+//                 core block, the slice waves carry one panel column and one panel row per thread in registers and emit the
+//                 factors U = K, Vf = G); the chain's loop is rolled so that its code stays in the instruction cache.
 //                 The state update state += K_v nu_v (:186-187) is row-local and goes out of place (state_out).
 // k_rank2v        the streaming pass: Sigma[r][c] -= sum_v (sequentially) K_v[r] G_v[c]; K through the scalar cache,
 //                 G in registers, 16 N^2 bytes per CALL (chunks of kCallV corrections per pass).
@@ -45,8 +46,8 @@ __device__ __forceinline__ constexpr int core5(int k, int v) { return k < 3 ? k 
 // diagnostics: stamp slot k of row `who` (0: lane 0 of the control wave, 1: lane 0 of the first slice wave)
 #define CF_TR(who, k)                                                                                              \
     do {                                                                                                           \
-        if (src.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 128 * (who) && (k) < kCoopTraceSlots)         \
-            src.trace[(who) * kCoopTraceSlots + (k)] = clock64();                                                  \
+        if (src.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 128 * (who) && (k) < kTraceSlots)         \
+            src.trace[(who) * kTraceSlots + (k)] = wall_clock64();                                                \
     } while (0)
 
 template <int SLICE>
@@ -307,34 +308,51 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
         wave_terms_s(lane, &sh_tv[v][0], pv.p.r_meas, s55, &sh_tv[v][10]);
         wave_sync_lds();
     };
-    if (w0 && cnt > 0) {   // prologue: correction 0 up to its gains
-        terms_h(0);
-        terms_s(0);
-        core_gains(0);
-    }
-    // step t -- phase 1: wave 0 evaluates the state-only half of correction t+1 (its landmark is already up to date:
-    // the core state was advanced with the gains of t) WHILE wave 1 applies correction t to the core block and the slices
-    // apply it to their panels and emit its factors; phase 2: wave 0 finishes correction t+1 (S, S^-1 from the updated
-    // block), its gains and the core state.  Two workgroup barriers per correction.
-#pragma unroll
-    for (int t = 0; t < kCallV; t++) {
-      if (t < cnt) {   // uniform (no break: the loop must unroll so that the panel registers are indexed statically)
-        __syncthreads();
-        CF_TR(0, 3 + 5 * t); CF_TR(1, 3 + 5 * t);
-        const int v = t;
-        if (w0) {
-            if (t + 1 < cnt) terms_h(t + 1);
-            CF_TR(0, 4 + 5 * t);
-        } else if (w1) {
+    // Three roles, each with its own loop over the corrections; every wave passes the same sequence of workgroup
+    // barriers -- A(t) in front of step t, B(t) behind its first phase when a correction t + 1 follows:
+    //   wave 0   the serial chain: phase 1 of step t = the state-only half of correction t + 1 (its landmark is up to
+    //            date: the core state was advanced with the gains of t); phase 2 = S, S^-1 from the updated block, the
+    //            gains and the core state of t + 1
+    //   wave 1   phase 1: the core block's own rank-2 update for correction t
+    //   slices   phase 1: factors of correction t for their index, panels and state updated
+    // The loops of waves 0 and 1 are ROLLED: the chain's code (atan2, sqrt, the quotients: ~1000 instructions per
+    // correction) is fetched once and then runs from the instruction cache.  Unrolled eight times -- as the slices' loop
+    // must be, their panels live in statically indexed registers -- the kernel was 17 k instructions of straight-line code
+    // that every workgroup fetched cold, correction after correction (3.3 us per correction against ~1.2 us for the chain).
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave == 0) {
+#pragma nounroll
+        for (int t = -1; t < cnt; t++) {   // (t = -1: the prologue, correction 0 up to its gains, no barrier yet)
+            if (t >= 0) { __syncthreads(); CF_TR(0, 3 + 5 * t); }
+            if (t + 1 < cnt) {
+                terms_h(t + 1);
+                if (t >= 0) { CF_TR(0, 4 + 5 * t); __syncthreads(); CF_TR(0, 5 + 5 * t); }
+                terms_s(t + 1);
+                core_gains(t + 1);
+                if (t >= 0) CF_TR(0, 6 + 5 * t);
+            }
+        }
+    } else if (wave == 1) {
+#pragma nounroll
+        for (int t = 0; t < cnt; t++) {
+            __syncthreads();
             // the core block's own rank-2 update (:191-192); compile-time divisor, positions beyond Nc hold zero factors
 #pragma unroll
             for (int q = 0; q < (kNcMax * kNcMax + 63) / 64; q++) {
                 const int e = lane + 64 * q;
                 const int j = e / kNcMax, c = e - j * kNcMax;
                 if (j < Nc && c < Nc)
-                    sh_Cb[j][c] = sh_Cb[j][c] - (sh_Kc[v][j][0] * sh_Gc[v][0][c] + sh_Kc[v][j][1] * sh_Gc[v][1][c]);
+                    sh_Cb[j][c] = sh_Cb[j][c] - (sh_Kc[t][j][0] * sh_Gc[t][0][c] + sh_Kc[t][j][1] * sh_Gc[t][1][c]);
             }
-        } else {
+            if (t + 1 < cnt) __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < kCallV; t++) {
+          if (t < cnt) {   // uniform (no break: the loop must unroll so that the panel registers are indexed statically)
+            __syncthreads();
+            CF_TR(1, 3 + 5 * t);
+            const int v = t;
             double H0[5], H1[5];
 #pragma unroll
             for (int k = 0; k < 5; k++) { H0[k] = sh_tv[v][k]; H1[k] = sh_tv[v][5 + k]; }
@@ -372,17 +390,9 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
             st_i = st_i + (k0 * sh_tv[v][14] + k1 * sh_tv[v][15]);   // :186
             if (i == 0) st_i = normalize_angle(st_i);                 // :187
             CF_TR(1, 4 + 5 * t);
+            if (t + 1 < cnt) __syncthreads();   // uniform
+          }
         }
-        if (t + 1 < cnt) {   // uniform
-            __syncthreads();
-            CF_TR(0, 5 + 5 * t);
-            if (w0) {
-                terms_s(t + 1);
-                core_gains(t + 1);
-                CF_TR(0, 6 + 5 * t);
-            }
-        }
-      }
     }
     CF_TR(0, 60); CF_TR(1, 60);
     if (slice && i < ld) {

@@ -67,7 +67,8 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
     c.init_flag = a.init_flag;
     c.tuning = a.tuning;
     c.touched_hwm = a.touched_hwm;
-    c.small_path = a.small_path;
+    EKFC(c.set_forms(a.forms));
+    c.tuning = a.tuning;
     c.active_set = a.active_set;
     c.pv.active_set = a.active_set;
     c.touched_bound = a.touched_bound;
@@ -75,14 +76,6 @@ ekf_status ekf_clone(ekf_handle h, ekf_handle* out) {
     HIPC(hipMemcpyAsync(c.pv.touch_flag, a.pv.touch_flag, (size_t)(a.pv.n > 0 ? a.pv.n : 1), hipMemcpyDeviceToDevice, c.stream));
     HIPC(hipMemcpyAsync(c.pv.touch_list, a.pv.touch_list, sizeof(int) * (size_t)(a.pv.n > 0 ? a.pv.n : 1), hipMemcpyDeviceToDevice, c.stream));
     HIPC(hipMemcpyAsync(c.pv.touch_count, a.pv.touch_count, sizeof(int), hipMemcpyDeviceToDevice, c.stream));
-    c.active_prefix = a.active_prefix;
-    c.fused = a.fused;
-    c.coop = a.coop;
-    c.call_fused = a.call_fused;
-    if (a.coop_target != c.coop_target) {
-        c.coop_target = a.coop_target;
-        c.coop_R = ekf::coop_rows_per_wg(c.pv.N, c.cus, c.coop_target);
-    }
     return c.sync();
 }
 
@@ -122,7 +115,7 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
             if (visible[i]) P.note_touched(i);
         return checked_launch();
     }
-    if (P.call_fused_ok() && !P.coop_ok()) {
+    if (P.call_fused_ok()) {
         // beyond the small-map path: the call is two launches whatever the number of visible landmarks -- the factor
         // panels of all its corrections, then ONE read-modify-write pass over Sigma (ekf_callfused.hip); bit-identical
         EKFC(P.ensure_callfused());
@@ -136,7 +129,7 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
         const int V = (int)vl.size() - 1;
         vl[0] = V;
         ekf::CallSrc cs{};
-        cs.trace = P.coop_trace;
+        cs.trace = P.phase_trace;
         const bool by_value = P.init_flag && V <= ekf::kCallV;   // the first call needs the whole sensor vector (:113-128)
         if (by_value) {
             cs.mode = ekf::SRC_INLINE;
@@ -169,56 +162,6 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
             EKFC(P.call_fused_pass(cs));
         }
         if (fold) P.pred_pending = false;
-        return checked_launch();
-    }
-    if (P.coop_ok()) {
-        // mid-size map (e.g. n = 200): the whole call -- and the prediction() before it -- in ONE launch with Sigma
-        // resident in the LDS of a few dozen workgroups, one workgroup-to-all hand-off per visible landmark (ekf_coop.hip)
-        EKFC(P.ensure_coop());
-        std::vector<int> vl(1, 0);
-        for (int i = 0; i < n; i++)
-            if (visible[i]) {
-                vl.push_back(i);
-                if (i + 1 > P.touched_hwm) P.touched_hwm = i + 1;
-                P.note_touched(i);
-            }
-        vl[0] = (int)vl.size() - 1;
-        ekf::CoopArgs ca{};
-        ca.inl_count = -1;
-        if (P.init_flag && vl[0] <= 8) {   // the readings of the visible landmarks travel by value: no host-to-device copy
-            ca.inl_count = vl[0];
-            for (int v = 0; v < vl[0]; v++) {
-                ca.inl_lm[v] = vl[1 + v];
-                ca.inl_xy[v][0] = sensor_xy[2 * vl[1 + v]];
-                ca.inl_xy[v][1] = sensor_xy[2 * vl[1 + v] + 1];
-            }
-        } else {
-            EKFC(P.upload2(P.coop_in, sensor_xy, sizeof(double) * 2 * n, vl.data(), sizeof(int) * vl.size()));
-        }
-        ca.sensor = P.coop_in;
-        ca.vlist = reinterpret_cast<const int*>(P.coop_in + 2 * (size_t)n);
-        ca.xchg = P.coop_xchg;
-        ca.flags = P.coop_flags;
-        ca.err = P.coop_err;
-        if (++P.coop_epoch == 0) P.coop_epoch = 1;
-        ca.epoch = P.coop_epoch;
-        ca.xstride = P.coop_xstride;
-        ca.rows_per_wg = P.coop_R;
-        ca.do_init = !P.init_flag;
-        ca.has_twist = P.pred_pending ? 1 : 0;
-        ca.dtheta = P.pred_dth;
-        ca.dx = P.pred_dx;
-        ca.sigma_next = P.sigma_alt;
-        ca.state_next = P.state_fz;
-        ca.trace = P.coop_trace;
-        EKFC(P.prof_begin(0));
-        ekf::launch_coop_measure(P.pv, ca, P.stream);
-        EKFC(P.prof_end());
-        std::swap(P.pv.sigma, P.sigma_alt);
-        std::swap(P.pv.state, P.state_fz);
-        P.alt_synced = false;
-        P.pred_pending = false;
-        P.init_flag = 1;
         return checked_launch();
     }
     EKFC(P.upload2(P.sensor_dev, sensor_xy, sizeof(double) * 2 * n, visible, (size_t)n));
@@ -345,18 +288,34 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     if (!delayed && P.pv.B == 1 && P.call_fused_ok() && active_dim(0) >= 1400) {
         EKFC(P.ensure_callfused());
         if (!P.terms) EKFC(P.dalloc(&P.terms, (size_t)(n > 0 ? n : 1) * 16));
+        if (!P.terms2) {
+            EKFC(P.dalloc(&P.terms2, (size_t)(n > 0 ? n : 1) * 16));
+            EKFC(P.dalloc(&P.scores2, (size_t)(n > 0 ? n : 1)));
+        }
         P.alt_synced = false;
+        auto m_bound = [&](int j) { return known_count + j < n ? known_count + j : n; };   // known count in front of reading j
         for (int j0 = 0; j0 < J; j0 += ekf::kCallV) {
             const int jc = J - j0 < ekf::kCallV ? J - j0 : ekf::kCallV;
+            // the first reading of a pass is scored by a launch of its own; every other one by its predecessor's launch
+            double *sc_in = P.scores, *tm_in = P.terms, *sc_out = P.scores2, *tm_out = P.terms2;
+            EKFC(P.prof_begin(1));
+            ekf::launch_assoc_score(P.pv, meas_xy[2 * j0], meas_xy[2 * j0 + 1], P.pv.assoc, P.cf_U, P.cf_V, 0, m_bound(j0), sc_in,
+                                    tm_in, P.stream);
+            EKFC(P.prof_end());
             for (int jj = 0; jj < jc; jj++) {
                 const int j = j0 + jj;
+                const int has_next = jj + 1 < jc;
                 EKFC(P.prof_begin(1));
-                ekf::launch_assoc_meas(P.pv, meas_xy[2 * j], meas_xy[2 * j + 1], P.pv.assoc, P.assoc_alt, P.assoc_out_dev + j, P.cf_state,
-                                       P.cf_U, P.cf_V, P.cf_cnt, jj, active_dim(j), jj == jc - 1 ? ekf::rank2v_round_count(jc) : 0,
-                                       known_count + j < n ? known_count + j : n, P.scores, P.terms, P.stream);
+                ekf::launch_assoc_reading(P.pv, meas_xy[2 * j], meas_xy[2 * j + 1], has_next, has_next ? meas_xy[2 * j + 2] : 0.0,
+                                          has_next ? meas_xy[2 * j + 3] : 0.0, P.pv.assoc, P.assoc_alt, P.assoc_out_dev + j,
+                                          P.cf_state, P.cf_U, P.cf_V, P.cf_cnt, jj, active_dim(j),
+                                          jj == jc - 1 ? ekf::rank2v_round_count(jc) : 0, m_bound(j + 1), sc_in, tm_in, sc_out,
+                                          tm_out, P.stream);
                 EKFC(P.prof_end());
                 std::swap(P.pv.state, P.cf_state);
                 std::swap(P.pv.assoc, P.assoc_alt);
+                std::swap(sc_in, sc_out);
+                std::swap(tm_in, tm_out);
             }
             ekf::PoolView view = P.pv;
             view.N = active_dim(j0 + jc - 1);
@@ -481,58 +440,30 @@ ekf_status ekf_set_active_set(ekf_handle h, int enable) {
     return EKF_OK;
 }
 
-ekf_status ekf_set_small_map_path(ekf_handle h, int enable) {
+ekf_status ekf_set_forms(ekf_handle h, unsigned forms) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
-    h->pool.small_path = enable ? 1 : 0;
+    return h->pool.set_forms(forms);
+}
+
+ekf_status ekf_get_forms(ekf_handle h, unsigned* forms) {
+    if (!h || !forms) return fail(EKF_ERR_INVALID, "null argument");
+    *forms = h->pool.forms;
     return EKF_OK;
 }
 
-ekf_status ekf_set_active_prefix(ekf_handle h, int enable) {
-    if (!h) return fail(EKF_ERR_INVALID, "null handle");
-    h->pool.active_prefix = enable ? 1 : 0;
-    return EKF_OK;
-}
-
-ekf_status ekf_set_fused_correction(ekf_handle h, int enable) {
-    if (!h) return fail(EKF_ERR_INVALID, "null handle");
-    h->pool.fused = enable ? 1 : 0;
-    h->pool.alt_synced = false;
-    return EKF_OK;
-}
-
-ekf_status ekf_set_call_fused(ekf_handle h, int enable) {
-    if (!h) return fail(EKF_ERR_INVALID, "null handle");
-    EKFC(h->pool.use());
-    h->pool.call_fused = enable ? 1 : 0;
-    return EKF_OK;
-}
-
-ekf_status ekf_set_cooperative_tick(ekf_handle h, int enable, int workgroups) {
-    if (!h) return fail(EKF_ERR_INVALID, "null handle");
-    Pool& P = h->pool;
-    EKFC(P.use());  // (a prediction deferred under the old setting happens now)
-    P.coop = enable ? 1 : 0;
-    P.coop_target = workgroups > 0 ? workgroups : 0;
-    P.coop_R = P.pv.B == 1 ? ekf::coop_rows_per_wg(P.pv.N, P.cus, P.coop_target) : 0;
-    return EKF_OK;
-}
-
-ekf_status ekf_cooperative_trace(ekf_handle h, int enable, long long* out, int* workgroups) {
+ekf_status ekf_phase_trace(ekf_handle h, int enable, long long* out) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     Pool& P = h->pool;
     EKFC(P.use());
-    const size_t cnt = (size_t)256 * ekf::kCoopTraceSlots;
-    if (out && P.coop_trace) {
-        EKFC(P.download(out, P.coop_trace, sizeof(long long) * cnt));
-        if (workgroups) *workgroups = P.coop_ok() ? (P.pv.N - 3 + P.coop_R - 1) / P.coop_R : 2;
-    }
-    if (enable && !P.coop_trace) {
-        EKFC(P.dalloc(&P.coop_trace, cnt));
-        HIPC(hipMemsetAsync(P.coop_trace, 0, sizeof(long long) * cnt, P.stream));
-    } else if (!enable && P.coop_trace) {
+    const size_t cnt = (size_t)2 * ekf::kTraceSlots;
+    if (out && P.phase_trace) EKFC(P.download(out, P.phase_trace, sizeof(long long) * cnt));
+    if (enable && !P.phase_trace) {
+        EKFC(P.dalloc(&P.phase_trace, cnt));
+        HIPC(hipMemsetAsync(P.phase_trace, 0, sizeof(long long) * cnt, P.stream));
+    } else if (!enable && P.phase_trace) {
         HIPC(hipStreamSynchronize(P.stream));
-        HIPC(hipFree(P.coop_trace));
-        P.coop_trace = nullptr;
+        HIPC(hipFree(P.phase_trace));
+        P.phase_trace = nullptr;
     }
     return EKF_OK;
 }
@@ -564,7 +495,7 @@ ekf_status ekf_sync(ekf_handle h) {
 
 ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal, int group_rows) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
-    h->pool.tuning = ekf::Rank2Tuning{rows_per_block, nontemporal, group_rows};
+    h->pool.set_tuning(rows_per_block, nontemporal, group_rows);
     return EKF_OK;
 }
 

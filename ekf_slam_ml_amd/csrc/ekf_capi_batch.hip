@@ -19,15 +19,20 @@ ekf_status ekf_batch_get_touched(ekf_batch_handle hb, int* counts_out) {
     return hb->pool.download(counts_out, hb->pool.pv.touch_count, sizeof(int) * hb->pool.pv.B);
 }
 
-ekf_status ekf_batch_set_small_map_path(ekf_batch_handle hb, int enable) {
+ekf_status ekf_batch_set_forms(ekf_batch_handle hb, unsigned forms) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
-    hb->pool.small_path = enable ? 1 : 0;
+    return hb->pool.set_forms(forms);
+}
+
+ekf_status ekf_batch_get_forms(ekf_batch_handle hb, unsigned* forms) {
+    if (!hb || !forms) return fail(EKF_ERR_INVALID, "null argument");
+    *forms = hb->pool.forms;
     return EKF_OK;
 }
 
-ekf_status ekf_batch_set_active_prefix(ekf_batch_handle hb, int enable) {
-    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
-    hb->pool.active_prefix = enable ? 1 : 0;
+ekf_status ekf_batch_form_counts(ekf_batch_handle hb, long long counts[6]) {
+    if (!hb || !counts) return fail(EKF_ERR_INVALID, "null argument");
+    for (int i = 0; i < 6; i++) counts[i] = hb->pool.form_counts[i];
     return EKF_OK;
 }
 
@@ -68,32 +73,13 @@ ekf_status ekf_batch_device_bytes(ekf_batch_handle hb, size_t* bytes) {
 
 ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal, int group_rows) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
-    hb->pool.tuning = ekf::Rank2Tuning{rows_per_block, nontemporal, group_rows};
-    return EKF_OK;
-}
-
-ekf_status ekf_batch_set_step_fused(ekf_batch_handle hb, int enable) {
-    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
-    hb->pool.step_fused = enable < 0 ? 0 : enable > 2 ? 1 : enable;   // 2: always the one-launch form
-    return EKF_OK;
-}
-
-ekf_status ekf_batch_set_call_fused(ekf_batch_handle hb, int enable) {
-    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
-    EKFC(hb->pool.use());
-    hb->pool.call_fused = enable ? 1 : 0;
+    hb->pool.set_tuning(rows_per_block, nontemporal, group_rows);
     return EKF_OK;
 }
 
 ekf_status ekf_batch_rank2_variant(ekf_batch_handle hb, int* group_rows, int* nontemporal, int* threads, int* rows_per_block) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
     ekf::rank2_variant(hb->pool.pv, hb->pool.tuning, group_rows, nontemporal, threads, rows_per_block);
-    return EKF_OK;
-}
-
-ekf_status ekf_batch_set_delayed_pairing(ekf_batch_handle hb, int enable) {
-    if (!hb) return fail(EKF_ERR_INVALID, "null handle");
-    hb->pool.delayed_pair = enable ? 1 : 0;
     return EKF_OK;
 }
 
@@ -246,6 +232,7 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
                 if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
                 if (P.active_set) ekf::launch_rank2_active(P.pv, P.tuning, P.touched_bound, P.stream);
                 else ekf::launch_rank2(P.pv, P.tuning, P.stream, true);
+                P.form_counts[4]++;
                 if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
                 k++;
             }
@@ -424,6 +411,7 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
                                               P.cf_U, P.cf_V, P.corr_counter, P.stream, P.cf_cnt, ekf::rank2v_round_count(smax));
                 if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
                 ekf::launch_rank2v(pva, P.cf_U, P.cf_V, P.cf_cnt, smax, P.tuning, P.stream);
+                P.form_counts[5]++;
             } else {
                 if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
                 ekf::launch_pool_step_unknown(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,

@@ -11,6 +11,8 @@
 // -ffp-contract=off), so the delayed path matches the eager path to rounding, not bit for bit.
 #include "ekf_kernels.hpp"
 
+#include <mutex>
+
 namespace ekf {
 
 constexpr int kMaxPending = 128;
@@ -532,6 +534,8 @@ __global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const
 constexpr int kStripWaves = 16;
 constexpr int kStripCols2 = 128;   // double2 columns per strip: lane l holds columns l and l + 64
 constexpr int kStripMaxVec = 80;   // pending vectors whose strip fits the 160 KB of LDS (2 KB each)
+constexpr int kStripFromCount = 40;        // automatic choice: the strip form beyond this many pending vectors ...
+constexpr int kStripMinWorkgroups = 512;   // ... on pools with at least this many strip workgroups (2 per CU)
 
 // `col` = the lane's first column (base + c); its second column is 64 double2 (1 KB) further on: one address register
 // pair per row serves both.  live0 / live1: lanes past the last column of the matrix take no part.
@@ -699,32 +703,37 @@ void launch_gain_delayed_pair(const PoolView& pv, const CmdSrc& src, const Pendi
     hipLaunchKernelGGL(k_gain_delayed_pair, dim3((pv.ld / 2 + 255) / 256, pv.B), dim3(256), 0, s, pv, src, pend, state_out);
 }
 
-void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s) {
-    if (pend.count <= 0) return;
+// dynamic LDS beyond 64 KB has to be allowed per kernel and per device: once each, whichever host thread comes first
+static bool strip_flush_allowed() {
+    constexpr int kMaxDev = 64;
+    static std::once_flag once[kMaxDev];
+    static bool ok[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return false;
+    std::call_once(once[dev], [dev]() {
+        const int bytes = kStripMaxVec * kStripCols2 * (int)sizeof(double2_t);
+        ok[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    });
+    return ok[dev];
+}
+
+int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s) {
+    if (pend.count <= 0) return 0;
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
     // Strip form: the V strip in LDS (count x 2 KB, one workgroup of 16 waves per CU) and >= 2 workgroups per CU of
-    // work.  Its time hardly depends on the count (45-47 ms at B = 4096, n = 1000: 5.5 TB/s -- workgroups that sweep a
-    // whole column strip stream ~10 % below workgroups dispatched in address order, and shorter row ranges pay the V
-    // staging once per range: 48.5 ms at 1024 rows, 52 at 512, 58 at 256), the plain form's does (41.5 ms up to 32
-    // vectors = the stream floor, 58.9 ms at 64: tools/flush_sweep.py) -- the strip form takes over beyond 40.
-    const bool forced = t.rows_per_block == -2;   // (tests: the strip form on pools of any size, any count <= 64)
-    if ((forced || (t.rows_per_block == 0 && pv.N >= 256 && pend.count > 40)) && pend.count <= kStripMaxVec) {
+    // work.  Its time hardly depends on the count, the plain form's does (the stream floor up to 32 vectors, 1.4x at
+    // 64: tools/flush_sweep.py) -- the strip form takes over beyond kStripFromCount vectors on pools that fill the chip.
+    const bool forced = t.strip_flush == 2;   // (EKF_FORM_STRIP_FLUSH_ALWAYS: pools of any size, any count <= 80)
+    if ((forced || (t.strip_flush == 1 && t.rows_per_block == 0 && pv.N >= 256 && pend.count > kStripFromCount)) &&
+        pend.count <= kStripMaxVec) {
         const int strips = (pv.ld / 2 + kStripCols2 - 1) / kStripCols2;
         int row_blocks = 1;
         while ((long long)pv.B * strips * row_blocks < 1024 && pv.N / (row_blocks * 2) >= 512) row_blocks *= 2;
-        // dynamic LDS beyond 64 KB has to be allowed per kernel and per device (once each)
-        static int attr_state[64];   // 0: not tried, 1: ok, 2: refused -> plain form
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        if (attr_state[dev] == 0)
-            attr_state[dev] = (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kStripMaxVec * kStripCols2 * 16) == hipSuccess &&
-                               hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flush_strip<false>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kStripMaxVec * kStripCols2 * 16) == hipSuccess)
-                                  ? 1 : 2;
-        const bool attr_ok = attr_state[dev] == 1;
-        if (attr_ok && (forced || (long long)pv.B * strips * row_blocks >= 512)) {
+        if ((forced || (long long)pv.B * strips * row_blocks >= kStripMinWorkgroups) && strip_flush_allowed()) {
             const int rows = (((pv.N + row_blocks - 1) / row_blocks) + 7) & ~7;
             row_blocks = (pv.N + rows - 1) / rows;
             dim3 grid((unsigned)((long long)strips * row_blocks * pv.B));
@@ -735,7 +744,7 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
             else hipLaunchKernelGGL((k_flush_strip<false>), grid, dim3(64 * kStripWaves), lds, s, pv.sigma, pend.U,
                                     pend.V, pv.N, pv.ld, pv.sigma_stride, pend.cap, pend.count, rows, strips,
                                     row_blocks, pv.B);
-            return;
+            return 1;
         }
     }
     int rows = t.rows_per_block > 0 ? t.rows_per_block : 16;  // measured: tools/flush_sweep.py
@@ -753,6 +762,7 @@ void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t,
         else hipLaunchKernelGGL((k_flush<8, false>), grid, dim3(256), 0, s, EKF_FL_ARGS);
     }
 #undef EKF_FL_ARGS
+    return 0;
 }
 
 int max_pending() { return kMaxPending; }

@@ -901,7 +901,7 @@ void rank2_variant(const PoolView& pv, const Rank2Tuning& t, int* u_out, int* nt
 // small pool that needs more workgroups than packing leaves)
 int rank2_packing(const PoolView& pv, const Rank2Tuning& t) {
     const int ld2n = pv.ld / 2;
-    if (t.rows_per_block < 0) return 1;                       // tuning escape: rows_per_block < 0 forces the plain kernel
+    if (!t.row_packing) return 1;                             // EKF_FORM_ROW_PACKING off: the plain kernel
     if (ld2n < 64) return 1;                                  // a wavefront may straddle at most two sub-rows
     if ((pv.N + 15) / 16 * 16 != pv.ld) return 1;             // a prefix view: columns beyond it must stay untouched
     auto util = [&](int P) { const long long w = (long long)P * ld2n; return (double)w / (double)((w + 255) / 256 * 256); };

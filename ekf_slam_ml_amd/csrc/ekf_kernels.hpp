@@ -331,6 +331,8 @@ struct Rank2Tuning {
     int rows_per_block;  // <= 0: automatic
     int nontemporal;     // < 0: automatic
     int group_rows;      // rows per load/store group U in {2,4,8}; other values: automatic
+    int row_packing;     // 1: narrow full-width views may take the row-packed kernel (EKF_FORM_ROW_PACKING)
+    int strip_flush;     // delayed mode: 0 never, 1 automatic, 2 always the strip-form flush (EKF_FORM_STRIP_FLUSH*)
 };
 
 void launch_init(const PoolView& pv, hipStream_t s);
@@ -346,7 +348,8 @@ void launch_gain_delayed(const PoolView& pv, const CmdSrc& src, const Pending& p
 void launch_gain_delayed_pair(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
                               hipStream_t s);
 // Sigma_base -= sum_j U[j] V[j]^T for j < pend.count (count even); the caller then resets count to 0.
-void launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s);
+// Returns the form taken: 0 plain (k_flush), 1 strip (k_flush_strip).
+int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s);
 // top of measurement(): pose snapshot (+ first-call landmark initialisation from init_xy [B][2n])
 void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init, hipStream_t s);
 void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s);
@@ -429,7 +432,7 @@ struct CallSrc {
     // in the kernel-argument segment -- no staging buffer, no host-to-device copy, no copy -> kernel dependency
     int inl_lm[kCallV];
     double inl_xy[kCallV][2];
-    long long* trace;              // nullable diagnostics: shader-clock stamps of workgroup 0 (ekf_cooperative_trace)
+    long long* trace;              // nullable diagnostics: clock stamps of workgroup 0, [2][kTraceSlots] (ekf_phase_trace)
     // has_twist != 0 (first pass of a single filter's call): the prediction() that precedes the call (ekf_slam.cpp:55-106)
     // is folded in -- k_call_factors applies At Sigma At^T + Q to its panels and the core on the fly and records
     // (A10, A20) in pred_out[b][2]; k_rank2v applies it to every other element before the corrections.  Nothing else
@@ -439,6 +442,7 @@ struct CallSrc {
     double* pred_out;              // [B][2]
 };
 enum : int { SRC_INLINE = 3 };
+constexpr int kTraceSlots = 64;
 // U, V: [B][2 * kCallV][ld] factor rows (K_v(:,0), K_v(:,1) / G_v(0,:), G_v(1,:)); cnt [B]: corrections of this pass
 void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, double* V, int* cnt, double* state_out,
                          hipStream_t s);
@@ -447,13 +451,18 @@ void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, doub
 void launch_rank2v(const PoolView& pv, const double* U, const double* V, const int* cnt, int vcount, const Rank2Tuning& t,
                    hipStream_t s, const double* pred = nullptr);
 
-// data_association() of a single filter with Sigma streamed once per call (ekf_assocfused.hip; the reading (mx, my) travels
-// by value): one reading = one launch
-// (scores against the stored covariance minus the call's pc pending pairs, decision, gain -> pair pc, state out of
-// place); the caller ends the call with launch_rank2v.  Nb: active dimension of the reading (discovered prefix).
-void launch_assoc_meas(const PoolView& pv, double mx, double my, const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j,
-                       double* state_out, double* U, double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound,
-                       double* scores, double* terms, hipStream_t s);
+// data_association() of a single filter with Sigma streamed once per call (ekf_assocfused.hip; readings travel by value).
+// launch_assoc_score: scores + correction terms of the FIRST reading of a pass against the stored covariance minus the pc
+// pending pairs.  launch_assoc_reading: reading (mx, my) -- decision from `scores` / `terms`, gain -> pair pc, state out of
+// place -- and, when has_next, the scores / terms of the next reading (mxn, myn) into scores_out / terms_out (m_bound_next:
+// host bound of the known count after this reading).  Nb: active dimension of the reading (discovered prefix).  The caller
+// ends the pass with launch_rank2v.
+void launch_assoc_score(const PoolView& pv, double mx, double my, const AssocRec* assoc_in, const double* U, const double* V,
+                        int pc, int m_bound, double* scores, double* terms, hipStream_t s);
+void launch_assoc_reading(const PoolView& pv, double mx, double my, int has_next, double mxn, double myn,
+                          const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j, double* state_out, double* U,
+                          double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound_next, const double* scores,
+                          const double* terms, double* scores_out, double* terms_out, hipStream_t s);
 int rank2v_round_count(int vcount);   // corrections per pass, rounded up to an instantiated count of k_rank2v
 
 // one step of an unknown-association log for every filter of a pool in ONE launch, any prefix size (ekf_stepfused.hip):
@@ -464,30 +473,6 @@ void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int*
                               int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s,
                               int* cnt_out = nullptr, int zero_upto = 0);
 
-// ---- one-launch prediction() + measurement() tick of a mid-size single filter, Sigma resident in LDS (ekf_coop.hip) ----
-struct CoopArgs {
-    const double* sensor;          // [2n] sensor_reading
-    const int* vlist;              // [1 + V]: V, then the visible landmarks in ascending order
-    double* xchg;                  // [n][xstride] hand-off slots: G (2 x ld) + 16 scalar terms per correction
-    unsigned* flags;               // [n] slot v is valid when flags[v] == epoch
-    unsigned* err;                 // host-mapped: != 0 after a hand-off timed out
-    unsigned epoch;                // unique per launch, never 0
-    int xstride;                   // doubles per slot (>= 2 * ld + 16)
-    int rows_per_wg;               // R, even
-    int do_init, has_twist;
-    double dtheta, dx;
-    double* sigma_next;
-    double* state_next;
-    int inl_count;                 // >= 0: the visible landmarks and their readings are given by value below (vlist, sensor unused)
-    int inl_lm[8];
-    double inl_xy[8][2];
-    long long* trace;              // nullable: [workgroups][kCoopTraceSlots] wall-clock stamps (100 MHz) of lane 0
-};
-constexpr int kCoopTraceSlots = 64;
-size_t coop_lds_bytes(int N, int rows_per_wg);
-int coop_rows_per_wg(int N, int cus, int target_wgs);   // 0: the map does not fit the LDS of the device
-hipError_t coop_prepare();
-void launch_coop_measure(const PoolView& pv, const CoopArgs& a, hipStream_t s);
 int max_pending();  // capacity limit of the delayed-update factor store (rows of U / V per filter)
 void launch_gather_poses(const PoolView& pv, double* out, hipStream_t s);
 

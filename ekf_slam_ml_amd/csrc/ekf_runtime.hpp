@@ -93,7 +93,7 @@ struct Pool {
     int device = -1;
     hipStream_t stream = nullptr;
     ekf::PoolView pv{};
-    ekf::Rank2Tuning tuning{0, -1, 0};
+    ekf::Rank2Tuning tuning{0, -1, 0, 1, 1};
     size_t dev_bytes = 0;
     int init_flag = 0;  // landmark_init_flag, ekf_slam.hpp:65
 
@@ -157,6 +157,8 @@ struct Pool {
     bool alt_synced = false;  // sigma_alt equals sigma outside the region the next fused correction rewrites
     ekf::AssocRec* assoc_alt = nullptr;  // "next" association record of the fused data_association() step
     double* terms = nullptr;             // [n][16] correction terms k_maha leaves for the winner
+    double* terms2 = nullptr;            // one launch per reading (ekf_assocfused.hip): terms / scores of the NEXT reading
+    double* scores2 = nullptr;
 
     // Optional per-launch HIP-event timing of a single filter's kernels (bench.py's configs[1] / configs[2] legs):
     // class 0 = launches that stream the covariance (fused correction, rank-2, decision + correction),
@@ -201,9 +203,9 @@ struct Pool {
     }
 
     // measurement() as two launches per call: factor panels + ONE streaming pass over Sigma (ekf_callfused.hip).
-    // Exact (bit-identical).  Default for single filters beyond the small-map path; opt-in for pools, whose eager
-    // per-landmark stream is the contract path the roofline is quoted on.
-    int call_fused = 0;
+    // Exact (bit-identical).  Default for single filters and pools beyond the small-map path (EKF_FORM_CALL_FUSED);
+    // bench.py switches it off for the eager per-landmark stream its `value` / `roofline` are quoted on.
+    int call_fused = 1;
     int step_fused = 1;            // pools, unknown association beyond the LDS-resident path: one launch per step
     double* cf_U = nullptr;        // [B][2 kCallV][ld] (+ slack)
     double* cf_V = nullptr;
@@ -233,45 +235,9 @@ struct Pool {
         if (ev0) HIPC(hipEventRecord(ev0, stream));
         EKFC(prof_begin(0));
         ekf::launch_rank2v(pv, cf_U, cf_V, cf_cnt, src.vcount, tuning, stream, src.has_twist ? cf_pred : nullptr);
+        form_counts[3]++;
         EKFC(prof_end());
         if (ev1) HIPC(hipEventRecord(ev1, stream));
-        return EKF_OK;
-    }
-
-    // One-launch prediction() + measurement() tick of a mid-size single filter with Sigma resident in LDS (ekf_coop.hip):
-    // opt-in (the two-launch call above is faster and needs no in-launch hand-offs)
-    int coop = 0;            // ekf_set_cooperative_tick
-    int coop_R = 0;          // rows per workgroup; 0 = the map does not fit (or not a single filter)
-    int coop_target = 0;     // requested number of workgroups (0 = default)
-    int cus = 0;
-    double* coop_in = nullptr;     // [2n] sensor_reading | [1 + n] ints: V, visible landmarks
-    double* coop_xchg = nullptr;   // [n][coop_xstride]
-    unsigned* coop_flags = nullptr;
-    unsigned* coop_err = nullptr;  // host-mapped word
-    unsigned coop_epoch = 0;
-    int coop_xstride = 0;
-    long long* coop_trace = nullptr;   // [256][kCoopTraceSlots], only while ekf_cooperative_trace is on
-    bool coop_ok() const {
-        return coop && coop_R > 0 && pv.B == 1 && pend_cap == 0 && !active_set && pv.n > 0 && pv.N > ekf::small_max_dim();
-    }
-    ekf_status ensure_coop() {
-        if (!sigma_alt) {  // the second covariance / state buffer the tick writes into (shared with the fused correction)
-            EKFC(dalloc(&sigma_alt, (size_t)pv.B * pv.sigma_stride));
-            EKFC(dalloc(&state_fz, (size_t)pv.B * pv.ld));
-            EKFC(dalloc(&assoc_alt, (size_t)pv.B));
-            EKFC(dalloc(&terms, (size_t)pv.B * (pv.n > 0 ? pv.n : 1) * 16));
-            alt_synced = false;
-        }
-        if (!coop_xchg) {
-            coop_xstride = 2 * pv.ld + 16;
-            EKFC(dalloc(&coop_in, (size_t)2 * pv.n + (size_t)(pv.n + 2 + 1) / 2));
-            EKFC(dalloc(&coop_xchg, (size_t)pv.n * coop_xstride));
-            EKFC(dalloc(&coop_flags, (size_t)pv.n));
-            HIPC(hipMemsetAsync(coop_flags, 0, sizeof(unsigned) * pv.n, stream));
-            HIPC(hipHostMalloc((void**)&coop_err, 64, hipHostMallocMapped));
-            *coop_err = 0;
-            HIPC(ekf::coop_prepare());
-        }
         return EKF_OK;
     }
 
@@ -292,6 +258,30 @@ struct Pool {
             alt_synced = true;
         }
         return EKF_OK;
+    }
+
+    // execution forms (ekf_set_forms): which launch structures may be taken where they apply
+    unsigned forms = EKF_FORMS_DEFAULT;
+    long long form_counts[6] = {0, 0, 0, 0, 0, 0};   // ekf_batch_form_counts
+    long long* phase_trace = nullptr;                // [2][kTraceSlots], only while ekf_phase_trace is on
+    ekf_status set_forms(unsigned f) {
+        EKFC(use());  // (a prediction deferred under the old setting happens now)
+        forms = f;
+        small_path = (f & EKF_FORM_SMALL_MAP) ? 1 : 0;
+        fused = (f & EKF_FORM_FUSED_CORRECTION) ? 1 : 0;
+        call_fused = (f & EKF_FORM_CALL_FUSED) ? 1 : 0;
+        active_prefix = (f & EKF_FORM_ACTIVE_PREFIX) ? 1 : 0;
+        step_fused = (f & EKF_FORM_STEP_FUSED) ? ((f & EKF_FORM_STEP_SPLIT_PASS) ? 1 : 2) : 0;
+        delayed_pair = (f & EKF_FORM_DELAYED_PAIR) ? 1 : 0;
+        tuning.row_packing = (f & EKF_FORM_ROW_PACKING) ? 1 : 0;
+        tuning.strip_flush = (f & EKF_FORM_STRIP_FLUSH_ALWAYS) ? 2 : (f & EKF_FORM_STRIP_FLUSH) ? 1 : 0;
+        alt_synced = false;
+        return EKF_OK;
+    }
+    void set_tuning(int rows_per_block, int nontemporal, int group_rows) {
+        tuning.rows_per_block = rows_per_block > 0 ? rows_per_block : 0;
+        tuning.nontemporal = nontemporal;
+        tuning.group_rows = group_rows;
     }
 
     ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count, pend_symmetric}; }
@@ -320,7 +310,7 @@ struct Pool {
     ekf_status flush() {
         if (pend_count > 0) {
             alt_synced = false;
-            ekf::launch_flush(pv, pending(), tuning, stream);
+            form_counts[ekf::launch_flush(pv, pending(), tuning, stream)]++;
             HIPC(hipGetLastError());
             pend_count = 0;
         }
@@ -334,6 +324,7 @@ struct Pool {
     int delayed_pair = 1;
     ekf_status correct_pair(const ekf::CmdSrc& src) {
         ekf::launch_gain_delayed_pair(pv, src, pending(), state_alt, stream);
+        form_counts[2]++;
         std::swap(pv.state, state_alt);
         pend_count += 4;
         return EKF_OK;
@@ -401,7 +392,7 @@ struct Pool {
     bool pred_pending = false;
     double pred_dth = 0.0, pred_dx = 0.0;
     bool defer_predict_ok() const {
-        return (pv.B == 1 && small_path && pend_cap == 0 && pv.n > 0 && pv.N <= ekf::small_max_dim()) || coop_ok() ||
+        return (pv.B == 1 && small_path && pend_cap == 0 && pv.n > 0 && pv.N <= ekf::small_max_dim()) ||
                (pv.B == 1 && call_fused_ok());
     }
     void launch_predict_now(double dth, double dx) {
@@ -413,9 +404,6 @@ struct Pool {
     }
     ekf_status use(bool settle = true) {
         HIPC(hipSetDevice(device));
-        if (coop_err && *coop_err)
-            return fail(EKF_ERR_HIP, "cooperative measurement tick gave up waiting for a hand-off (slot " +
-                                         std::to_string(*coop_err - 1) + "): the filter state is invalid");
         if (settle && pred_pending) {
             pred_pending = false;
             launch_predict_now(pred_dth, pred_dx);
@@ -454,9 +442,6 @@ struct Pool {
         pv.ld = round_up(pv.N, 16);
         pv.B = B;
         pv.sigma_stride = (size_t)pv.N * pv.ld;
-        cus = prop.multiProcessorCount;
-        call_fused = B == 1 ? 1 : 0;
-        coop_R = B == 1 ? ekf::coop_rows_per_wg(pv.N, cus, coop_target) : 0;
         EKFC(dalloc(&pv.sigma, (size_t)B * pv.sigma_stride));
         EKFC(dalloc(&pv.state, (size_t)B * pv.ld));
         EKFC(dalloc(&pv.Kg, (size_t)B * 2 * pv.ld));
@@ -497,11 +482,9 @@ struct Pool {
                         pv.touch_count, scores, meas_dev,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, sigma_alt, state_fz, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
-                        coop_in, coop_xchg, coop_flags, coop_trace, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred};
+                        phase_trace, terms2, scores2, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
-        if (coop_err) (void)hipHostFree(coop_err);
-        coop_err = nullptr;
         stage_in.release();
         stage_out.release();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);

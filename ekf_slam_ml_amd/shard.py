@@ -36,6 +36,17 @@ def reduce_throughput(wall_s: float, corrections: float, filter_steps: float, de
     return float(tmax.item()), float(sums[0].item()), float(sums[1].item())
 
 
+def wall_spread(wall_s: float, device="cpu"):
+    """(min, max) over ranks of a rank-local wall time: a straggler shows up as a gap between the two."""
+    dist = _dist()
+    if dist is None:
+        return wall_s, wall_s
+    import torch
+    t = torch.tensor([wall_s, -wall_s], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(-t[1].item()), float(t[0].item())
+
+
 def count_ranks(device="cpu"):
     """Number of ranks that took part in the job, by an all-reduce of ones (1 without a process group): the bench line
     reports it so that a multi-GPU figure can be told from one rank's."""

@@ -104,22 +104,55 @@ ekf_status ekf_get_cov(ekf_handle h, double* out /* N*N row-major */);
 ekf_status ekf_set_cov(ekf_handle h, const double* in /* N*N row-major */);
 ekf_status ekf_get_init_flag(ekf_handle h, int* flag);  /* landmark_init_flag, ekf_slam.hpp:65 */
 ekf_status ekf_set_init_flag(ekf_handle h, int flag);
-/* data_association() appends landmarks in discovery order, so its corrections are exactly confined to the
- * leading (3 + 2*known_count) block of the state; enable != 0 (default) streams only that block. Results are
- * bit-identical to enable == 0 for finite states. */
-ekf_status ekf_set_active_prefix(ekf_handle h, int enable);
-ekf_status ekf_batch_set_active_prefix(ekf_batch_handle hb, int enable);
-/* LDS-resident forms of the batch runs (enable != 0, default; bit-identical to the multi-kernel replay):
- *   ekf_batch_run_known   N = 3 + 2n <= 104 (e.g. the reference's n = 20) and vmax <= 64: the WHOLE step range is
- *                         one launch, every filter's covariance staying in LDS from the first step to the last;
- *   ekf_batch_run_unknown while every filter's discovered prefix fits (3 + 2*(known_count + readings of the
- *                         step) <= 104): one launch per step instead of four launches per measurement slot. */
-ekf_status ekf_batch_set_small_map_path(ekf_batch_handle hb, int enable);
-/* Single filter, maps beyond the small-map path: every eager correction (gain K, state, covariance) runs as
- * ONE launch that writes Sigma - K(H Sigma) out of place into a second buffer; the two buffers swap after
- * each correction (enable != 0, default).  enable == 0: the two-launch form (gain, then the in-place rank-2
- * stream) that the batch pools use.  Bit-identical; costs a second N x N buffer. */
-ekf_status ekf_set_fused_correction(ekf_handle h, int enable);
+/* ---- execution forms (test / measurement hook; a caller never needs it) -----------------------------------------
+ * Every entry point computes ONE function -- the reference's -- but the library holds several launch structures
+ * ("forms") for it and picks among them by map size and pool size (DESIGN.md section 4, table "path selection").
+ * All exact forms are bit-identical to each other; the tests switch them off one by one and compare bit for bit.
+ * A bit set = the form may be taken where it applies (default: EKF_FORMS_DEFAULT = all but the ALWAYS hook). */
+typedef enum {
+    /* N = 3 + 2n <= 104 (the reference's own n = 20): a whole measurement() / data_association() call, a whole step of
+     * a pool (while 3 + 2*(known_count + readings) <= 104) or a whole run of a known-association log is ONE launch with
+     * Sigma resident in LDS (ekf_small.hip).  Off: the multi-kernel chain. */
+    EKF_FORM_SMALL_MAP = 1u << 0,
+    /* single filter, per-landmark path: gain + state + covariance of a correction (and decision + correction of an
+     * association) in ONE launch that writes Sigma - K(H Sigma) out of place into a second N x N buffer (ekf_fused.hip).
+     * Off: gain launch + in-place rank-2 stream, as pools do. */
+    EKF_FORM_FUSED_CORRECTION = 1u << 1,
+    /* beyond the small-map path: measurement() as TWO launches per call whatever the number of visible landmarks --
+     * the gains K_v and rows H_v Sigma of all the call's corrections from two thin panels of Sigma, then ONE
+     * read-modify-write pass in which every element takes its V rank-2 corrections in order: 16 N^2 bytes per CALL
+     * (per 8 corrections) instead of per landmark (ekf_callfused.hip); a single filter's data_association() as one launch
+     * per reading + one pass per call (ekf_assocfused.hip).  Off: one covariance stream per landmark -- the eager
+     * contract stream bench.py quotes `value` / `roofline` on. */
+    EKF_FORM_CALL_FUSED = 1u << 2,
+    /* data_association() appends landmarks in discovery order, so its corrections are exactly confined to the leading
+     * 3 + 2*known_count block of the state: stream only that block.  Off: full width. */
+    EKF_FORM_ACTIVE_PREFIX = 1u << 3,
+    /* pools, ekf_batch_run_unknown beyond the LDS-resident path, <= 8 reading slots per step: one launch per STEP (a
+     * workgroup per filter scores, decides and builds the gains against the stored covariance minus the step's pending
+     * pairs; ekf_stepfused.hip).  Off: four launches per reading slot. */
+    EKF_FORM_STEP_FUSED = 1u << 4,
+    /* ... and when the discovered prefixes are big, the step's covariance pass as a second launch spread over the chip. */
+    EKF_FORM_STEP_SPLIT_PASS = 1u << 5,
+    /* delayed mode, ekf_batch_run_known: the two corrections of a step in ONE gain launch (pending factors read once). */
+    EKF_FORM_DELAYED_PAIR = 1u << 6,
+    /* narrow maps: P consecutive rows streamed as one virtual row that fills the 256-lane strips (k_rank2_packed). */
+    EKF_FORM_ROW_PACKING = 1u << 7,
+    /* delayed mode: the strip-form flush (V strip in LDS) beyond 40 pending vectors on pools that fill the chip. */
+    EKF_FORM_STRIP_FLUSH = 1u << 8,
+    /* test hook: the strip-form flush on pools of any size, for any count <= 80 vectors. */
+    EKF_FORM_STRIP_FLUSH_ALWAYS = 1u << 9,
+    EKF_FORMS_DEFAULT = (1u << 9) - 1
+} ekf_form;
+ekf_status ekf_set_forms(ekf_handle h, unsigned forms);
+ekf_status ekf_get_forms(ekf_handle h, unsigned* forms);
+ekf_status ekf_batch_set_forms(ekf_batch_handle hb, unsigned forms);
+ekf_status ekf_batch_get_forms(ekf_batch_handle hb, unsigned* forms);
+/* Test hook: covariance passes of each form this pool has launched since it was created --
+ * counts[0] plain flush, [1] strip-form flush, [2] paired delayed gain launches, [3] call-fused passes,
+ * [4] per-landmark rank-2 streams, [5] step-fused launches with a separate pass. */
+ekf_status ekf_batch_form_counts(ekf_batch_handle hb, long long counts[6]);
+
 /* Active-set covariance update (opt-in, default 0; reported separately from the dense contract path):
  * the eager correction streams only the rows of the TOUCHED set -- the pose rows and the rows of landmarks
  * that have ever been corrected.  Every other row has K(r,:) = 0 exactly (its landmark still carries the
@@ -129,43 +162,11 @@ ekf_status ekf_set_active_set(ekf_handle h, int enable);
 ekf_status ekf_batch_set_active_set(ekf_batch_handle hb, int enable);
 /* Size of every filter's touched set (landmarks corrected at least once): counts_out[B]. */
 ekf_status ekf_batch_get_touched(ekf_batch_handle hb, int* counts_out);
-/* Small maps (N = 3 + 2n <= 104, e.g. the reference's n = 20): measurement() runs as ONE single-workgroup,
- * LDS-resident launch instead of 2 launches per visible landmark; enable != 0 is the default.  Bit-identical
- * to the multi-kernel path. */
-ekf_status ekf_set_small_map_path(ekf_handle h, int enable);
-/* measurement() as TWO launches per call, whatever the number of visible landmarks (maps beyond the small-map path):
- * the Kalman gains K_v and the rows H_v Sigma of ALL the call's corrections are obtained from two thin panels of Sigma
- * (the rows and the columns of the pose and of the visible landmarks: O(V^2 N) work), then every element of Sigma takes
- * its V rank-2 corrections, in order, in ONE read-modify-write pass: 16 N^2 bytes per CALL instead of per landmark, and
- * still bit-identical to the per-landmark path (ekf_slam.cpp:132-194).  Calls with more than 8 visible landmarks take
- * one pass per 8.  Default: on for a single filter; off for pools (ekf_batch_run_known), whose per-landmark stream is
- * the contract path of the roofline figure -- switch it on there to halve (V = 2) the traffic of a step. */
-ekf_status ekf_set_call_fused(ekf_handle h, int enable);
-ekf_status ekf_batch_set_call_fused(ekf_batch_handle hb, int enable);
-/* Pools, ekf_batch_run_unknown with at most 8 reading slots per step, discovered prefixes beyond the LDS-resident path
- * (3 + 2 * known > 104): one launch per STEP -- a workgroup per filter scores, decides and builds the gains of the step's
- * readings against the stored covariance minus the step's pending rank-2 pairs, and streams the filter's prefix ONCE at
- * the end of the step (enable == 1, default).  When the prefixes are big (launch bound N >= 603, known counts fresh, and
- * at least 70 % of B * N^2 is discovered prefix) the step takes TWO launches instead: the same kernel stops at the factor
- * pairs and one streaming pass over all filters (the rank-2 kernel's tiling, every filter spread over the chip) applies
- * them -- enable == 2 keeps to the one-launch form.  enable == 0: four launches per measurement slot (scores, decision,
- * gain, rank-2 stream).  All three bit-identical. */
-ekf_status ekf_batch_set_step_fused(ekf_batch_handle hb, int enable);
-/* Single filter, mid-size maps (104 < N = 3 + 2n, as long as N rows of Sigma spread over the device's CUs fit their
- * LDS: n up to about 700): ekf_predict + ekf_measure_known of one node tick run as ONE launch -- the rows of Sigma are
- * split over `workgroups` workgroups (0 = automatic, about 50; at most one per CU) that keep them in LDS for all the
- * visible landmarks of the call and exchange one 2 x N block per landmark inside the launch (enable != 0; default OFF:
- * the two-launch call above is faster -- profiles/r02/coop_handoff_trace.txt).
- * ekf_predict then launches nothing by itself: the twist rides along with the next ekf_measure_known (any other call
- * in between makes the pending prediction happen first).  enable == 0: one launch per landmark (ekf_set_fused_correction).
- * Bit-identical either way. */
-ekf_status ekf_set_cooperative_tick(ekf_handle h, int enable, int workgroups);
-/* Diagnostics of the cooperative tick: while enabled, lane 0 of every workgroup stamps the device's 100 MHz wall clock at
- * its phase boundaries.  out (nullable) receives the stamps of the LAST tick, [256][64] (row = workgroup; slots: 0 start,
- * 1 image loaded, 2 prediction done, 3 readings converted, then for correction v < 9 at 4 + 6v: begin, terms ready
- * (owner) / flag seen (others), block published / loaded, K ready, rows updated; 62 loop done, 63 written back);
- * workgroups (nullable) = workgroups in use. */
-ekf_status ekf_cooperative_trace(ekf_handle h, int enable, long long* out, int* workgroups);
+/* Diagnostics of the two-launch measurement() call: while enabled, lane 0 of the control wave (row 0) and of the first
+ * slice wave (row 1) of workgroup 0 of k_call_factors stamp the 100 MHz wall clock at their phase boundaries.  out (nullable)
+ * receives the stamps of the LAST call, [2][64] (slots: 0 start, 1 gathers issued, 2 prediction folded, then per
+ * correction t at 3 + 5t: barrier passed, terms / panel update done, second barrier passed, gains done; 60 loop done). */
+ekf_status ekf_phase_trace(ekf_handle h, int enable, long long* out);
 /* Blocks until every kernel queued on the handle's stream has finished. */
 ekf_status ekf_sync(ekf_handle h);
 /* Measurement hook (off by default): brackets every covariance-streaming launch (class 0: fused correction, rank-2
@@ -251,9 +252,8 @@ ekf_status ekf_batch_get_poses(ekf_batch_handle hb, double* out);
 ekf_status ekf_batch_checksum(ekf_batch_handle hb, double out[4]);
 
 /* Tuning knobs of the covariance rank-2 kernel: rows per workgroup, non-temporal access (0/1),
- * rows per load/store group (2, 4 or 8).  0 (nontemporal: < 0) restores the automatic choice; rows_per_block -1
- * keeps to the plain kernels (no row packing, no strip-form flush), -2 takes the strip-form flush of the delayed
- * update on pools of any size (up to 80 pending vectors).  Results do not depend on them, bit for bit. */
+ * rows per load/store group (2, 4, 8 or 16).  0 (nontemporal: < 0) restores the automatic choice.
+ * Results do not depend on them, bit for bit. */
 ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int nontemporal, int group_rows);
 /* Report hook: the instantiation ekf::k_rank2<group_rows, nontemporal, threads> and the rows per workgroup that a
  * full-width eager correction of this pool launches (bench.py ties its PMC traffic record to this name). */
@@ -336,11 +336,6 @@ ekf_status ekf_batch_mc_stats(ekf_batch_handle hb, int t, double out[6]);
  * rounding (measured asymmetry 1e-18 relative), so results still agree at 1e-9. */
 ekf_status ekf_set_update_mode(ekf_handle h, int max_pending_corrections, int symmetric_gather);
 ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections, int symmetric_gather);
-/* Delayed mode, ekf_batch_run_known: two consecutive log slots of a step (two landmarks of one measurement() call) are
- * corrected by ONE launch that reads the pending factor rows once for both (enable != 0, default) instead of one launch
- * per landmark.  Same results to rounding (the mode's tolerance, 1e-9 against the reference semantics). */
-ekf_status ekf_batch_set_delayed_pairing(ekf_batch_handle hb, int enable);
-
 /* ---- dense general-F covariance propagation, fp32 on the matrix cores (BASELINE.json configs[3]) ----
  * Sigma <- F * Sigma * F^T + Q for an ARBITRARY dense F: the reference's expression
  * `sigma = At*sigma*At.t() + Q` (ekf_slam.cpp:101-102) as Armadillo executes it (two dense N^3

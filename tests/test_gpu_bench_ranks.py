@@ -89,3 +89,51 @@ print("rccl ok")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), EKF_ROOT=ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+def _bench(extra, env=None, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
+                       timeout=timeout, env=env or dict(os.environ), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return _line(r.stdout)
+
+
+def test_consistency_and_delayed_parity_on_the_drivers_command_line():
+    """`--steps 20 --warmup 5` (the driver's arguments) rounds the delayed leg to 32 steps, so the log is longer than the
+    contract leg's run: the Monte-Carlo consistency figures must still be taken at the step the pool stands at (NEES of
+    the same order as for `--steps 16 --warmup 4`, where both legs run the same steps), and the delayed leg must carry its
+    own parity figures at its own step count."""
+    side = ["--filters", "64", "--no-active-set", "--no-unknown", "--no-small", "--no-configs", "--no-call-fused",
+            "--cpu-filters", "4"]
+    a = _bench(["--steps", "20", "--warmup", "5"] + side)
+    b = _bench(["--steps", "16", "--warmup", "4"] + side)
+    for d, last in ((a, 25), (b, 20)):
+        mc = d["mc_consistency"]
+        assert mc["step"] == last
+        assert 0.5 < mc["nees_mean"] < 30.0 and mc["rmse_xy"] < 0.2 and mc["frac_nees_below_95pct"] > 0.3, mc
+    assert 1 / 3 < a["mc_consistency"]["nees_mean"] / b["mc_consistency"]["nees_mean"] < 3
+    for d, kd in ((a, 32), (b, 16)):
+        dl = d["delayed_update"]
+        assert dl["steps"] == kd and dl["parity_step"] == d["warmup"] + kd
+        assert dl["max_abs_state_diff_vs_eager"] < 1e-9 and dl["max_rel_cov_diff_vs_eager"] < 1e-9
+        assert dl["max_abs_state_diff_vs_cpu_port"] < 1e-9 and dl["max_rel_cov_diff_vs_cpu_port"] < 1e-9
+
+
+def test_four_ranks_with_unequal_shards():
+    """4 ranks (gloo rendezvous on the one GPU of the test box) over a job of 4 * 24 + 3 filters: blocks of 25, 25, 25 and
+    24 filters by global id; the aggregate counts every filter once and the line shows the per-rank spread."""
+    total = 4 * 24 + 3
+    env = dict(os.environ, EKF_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    args = ["--steps", "3", "--warmup", "1", "--filters", "25", "--total-filters", str(total), "--landmarks", "300",
+            "--delayed-k", "0", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "4"] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 4 and d["config"]["ranks_seen"] == 4 and d["config"]["filters_total"] == total
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (total * 2) - 1.0) < 1e-9     # every filter counted once
+    assert d["rank_ms_per_step_min"] <= d["rank_ms_per_step_max"] == d["ms_per_step"]
+    # side legs are not run at N > 1
+    for key in ("call_fused_update", "active_set_update", "unknown_association", "small_map_monte_carlo", "configs_1"):
+        assert key not in d, key

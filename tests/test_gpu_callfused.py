@@ -20,7 +20,6 @@ def _replay(f, log, t0, t1):
 
 def _single(hip, n, call_fused):
     f = hip.EKF_SLAM(n)
-    f.set_cooperative_tick(False)
     f.set_call_fused(call_fused)
     return f
 

@@ -177,20 +177,23 @@ def test_delayed_data_association_without_flush(hip, oracle, k):
 def test_strip_form_flush_is_bit_identical_to_the_plain_flush(hip, B, n, k, vmax):
     """k_flush_strip (pools that fill the chip: V strip in LDS, 8 rows x 4 columns per lane, 4-vector scalar batches)
     applies the pending pairs to every element in the same order with the same fused multiply-adds as k_flush: forced
-    here on small pools (set_tuning(rows_per_block=-2)) and compared bit for bit -- strips that end inside the matrix
+    here on small pools (set_strip_flush("always"): EKF_FORM_STRIP_FLUSH_ALWAYS) and compared bit for bit -- strips that end inside the matrix
     (ld/2 not a multiple of 128), N not a multiple of 8 (partial last group), pending counts that are not a
     multiple of 4 (k odd with one correction per step) and ragged counts across filters (zero pairs)."""
     cfg = synth.SimConfig(n=n, steps=2 * k + 3, filters=B, seed=4000 + n, half_extent=4.0, min_spacing=0.15,
                           max_visible_dis=1e9 if vmax == 1 else 2.0, vmax=vmax)
     log = synth.make_known_log(cfg)
     res = []
-    for rows in (-2, -1, 16):
+    for strip, rows in (("always", 0), ("never", 0), ("never", 16)):
         bt = hip.BatchEKF(B, n)
         bt.set_update_mode(k)
+        bt.set_strip_flush(strip)
         bt.set_tuning(rows_per_block=rows)
         bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
         st = bt.run_known(0, cfg.steps, time_kernels=True)
         assert st["rank2_launches"] >= 2
+        fc = bt.form_counts()
+        assert (fc["flush_strip"], fc["flush_plain"]) == ((st["rank2_launches"], 0) if strip == "always" else (0, st["rank2_launches"]))
         res.append(([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)]))
         bt.close()
     for other in (1, 2):
@@ -259,3 +262,29 @@ def test_paired_delayed_gain_steps_random_shapes(hip, oracle):
         for t in range(T):
             o.prediction(*log.twist[t, 0]); o.measurement_compact(log.init_xy[0], log.lm_idx[t, 0], log.z_xy[t, 0])
         assert_parity(outs[0][0][0], outs[0][1][0], o.state, o.cov, FP64_TOL, f"shape {idx} vs checker")
+
+
+def test_delayed_at_the_million_steps_configuration(hip, oracle):
+    """The exact configuration of bench.py's >= 1e6 update steps/s leg (ekf_slam.cpp:178-192 at n = 1000): k = 32
+    corrections per flush, the two corrections of a step in one gain launch (k_gain_delayed_pair), and a pool big enough
+    (B = 128: 1024 strip workgroups) that launch_flush takes the strip form BY ITSELF at 64 pending vectors -- asserted
+    through the form counters, not forced.  17 steps = 34 corrections per filter: one automatic flush at 32 (strip form)
+    and the run's closing flush of 2 (plain form); three filters against the structured checker at 1e-9."""
+    B, n, k, T = 128, 1000, 32, 18
+    log = synth.make_known_log(synth.config5(filters=B, steps=T, n=n))
+    assert ((log.lm_idx[1:] >= 0).sum(axis=2) == 2).all()   # V = 2 everywhere: every step is one paired launch
+    bt = hip.BatchEKF(B, n)
+    bt.set_update_mode(k)
+    assert bt.forms == hip.FORMS_DEFAULT                    # nothing forced
+    bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+    st = bt.run_known(0, T, time_kernels=True)
+    assert st["corrections"] == B * 34 and st["rank2_launches"] == 2
+    fc = bt.form_counts()
+    assert fc["flush_strip"] == 1 and fc["flush_plain"] == 1 and fc["gain_pairs"] == T - 1, fc
+    for b in (0, 61, B - 1):
+        o = oracle.OracleEKF(n, oracle.STRUCTURED)
+        for t in range(T):
+            o.prediction(*log.twist[t, b])
+            o.measurement_compact(log.init_xy[b], log.lm_idx[t, b], log.z_xy[t, b])
+        assert_parity(bt.state(b), bt.cov(b), o.state, o.cov, FP64_TOL, f"filter {b}")
+    bt.close()

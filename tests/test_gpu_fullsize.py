@@ -10,10 +10,13 @@ from parity import FP64_TOL, assert_parity
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def batch1000(hip):
+@pytest.fixture(scope="module", params=["stream", "call_fused"])
+def batch1000(hip, request):
+    """both exact forms of a pool's measurement(): the eager per-landmark stream (bench.py's contract leg) and the
+    default, one pass over Sigma per call"""
     log = synth.make_known_log(synth.config5(filters=12, steps=6, n=1000))
     bt = hip.BatchEKF(12, 1000)
+    bt.set_call_fused(request.param == "call_fused")
     bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
     stats = bt.run_known(0, 6, time_kernels=True)
     yield log, bt, stats
@@ -23,7 +26,9 @@ def batch1000(hip):
 def test_batch_n1000_vs_structured_oracle(batch1000, oracle):
     log, bt, stats = batch1000
     assert stats["corrections"] == 12 * 5 * 2 and stats["filter_steps"] == 72
-    assert abs(stats["rank2_bytes_per_launch"] - 12 * 16 * 2003.0 ** 2) < 1.0  # 2*8*N^2 per correction
+    assert abs(stats["rank2_bytes_per_launch"] - 12 * 16 * 2003.0 ** 2) < 1.0  # 2*8*N^2 per correction (per call)
+    fc = bt.form_counts()
+    assert (fc["rank2_streams"], fc["call_fused_passes"]) in ((10, 0), (0, 5))
     for b in (0, 7, 11):
         o = oracle.OracleEKF(1000, oracle.STRUCTURED)
         for t in range(6):

@@ -21,7 +21,7 @@ def _scenario(hip, oracle, seed):
     f.set_fused_correction(bool(rng.integers(0, 2)))
     rng2 = np.random.default_rng(seed + 7919)   # (a second stream: the scenarios of round 1 keep their inputs)
     f.set_call_fused(bool(rng2.integers(0, 2)))                                   # two launches per measurement() call
-    f.set_cooperative_tick(bool(rng2.integers(0, 2)), int(rng2.choice([0, 3, 17, 64])))   # one-launch LDS-resident tick
+    rng2.integers(0, 2), rng2.choice([0, 3, 17, 64])   # (draws of a path that left the library: the scenarios keep their inputs)
     world = rng.uniform(-2.5, 2.5, size=(n, 2))
     world[np.hypot(world[:, 0], world[:, 1]) < 0.3] += 0.6          # keep landmarks off the start pose
     pose = np.zeros(3)                                              # true (theta, x, y)
@@ -33,7 +33,7 @@ def _scenario(hip, oracle, seed):
         if rng2.random() < 0.1:
             f.set_call_fused(bool(rng2.integers(0, 2)))
         if rng2.random() < 0.1:
-            f.set_cooperative_tick(bool(rng2.integers(0, 2)), int(rng2.choice([0, 3, 17, 64])))
+            rng2.integers(0, 2), rng2.choice([0, 3, 17, 64])
         if rng.random() < 0.05:
             mode = int(rng.choice([0, 3, 16]))
             f.set_update_mode(mode, symmetric_gather=False)

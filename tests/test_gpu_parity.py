@@ -345,20 +345,22 @@ def test_invalid_arguments_are_reported(hip):
 
 # ---- batch of independent filters (configs[4] shape, reduced) -------------------------------------
 
-def _batch(hip, log):
+def _batch(hip, log, call_fused=True):
     cfg = log.cfg
     b = hip.BatchEKF(cfg.filters, cfg.n)
+    b.set_call_fused(call_fused)   # False: the eager per-landmark stream (bench.py's contract leg)
     b.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
     return b
 
 
-def test_batch_equals_single_filters_bitwise(hip):
+@pytest.mark.parametrize("call_fused", [False, True])
+def test_batch_equals_single_filters_bitwise(hip, call_fused):
     log = synth.make_known_log(synth.config5(filters=5, steps=8, n=60))
-    bt = _batch(hip, log)
+    bt = _batch(hip, log, call_fused)
     st = bt.run_known(0, 3)
     st2 = bt.run_known(3, 8, time_kernels=True)
     assert st["corrections"] + st2["corrections"] == log.corrections
-    assert st2["rank2_launches"] == 10 and st2["rank2_ms"] > 0
+    assert st2["rank2_launches"] == (5 if call_fused else 10) and st2["rank2_ms"] > 0
     for b in range(5):
         f = hip.EKF_SLAM(60)
         for t in range(8):
@@ -371,14 +373,15 @@ def test_batch_equals_single_filters_bitwise(hip):
     bt.close()
 
 
-def test_batch_ragged_slots_vs_oracle(hip, oracle):
+@pytest.mark.parametrize("call_fused", [False, True])
+def test_batch_ragged_slots_vs_oracle(hip, oracle, call_fused):
     """Filters see different numbers of landmarks per step (-1 padded slots)."""
     cfg = synth.SimConfig(n=40, steps=30, filters=6, seed=123, half_extent=2.0, min_spacing=0.2,
                           max_visible_dis=0.8, vmax=5)
     log = synth.make_known_log(cfg)
     counts = (log.lm_idx >= 0).sum(axis=2)
     assert counts.min() < counts.max()
-    bt = _batch(hip, log)
+    bt = _batch(hip, log, call_fused)
     bt.run_known()
     st, cv, _ = oracle.batch_run_known(log, oracle.STRUCTURED, want_cov=True, fast=False)
     for b in range(6):
@@ -532,14 +535,15 @@ def test_device_normalize_angle_bit_exact(hip, oracle):
 @pytest.mark.parametrize("n,B", [(200, 64), (100, 200), (60, 540), (333, 24)])
 def test_row_packed_rank2_is_bit_identical(hip, n, B):
     """Pools of narrow maps take the row-packed rank-2 kernel (P rows side by side fill the 256-lane strips; ragged last
-    virtual row when N % P != 0, wavefronts straddling two sub-rows).  rows_per_block < 0 forces the plain kernel."""
+    virtual row when N % P != 0, wavefronts straddling two sub-rows).  set_row_packing(False) (EKF_FORM_ROW_PACKING off) forces the plain kernel."""
     cfg = synth.config5(filters=B, steps=7, n=n)
     cfg.max_visible_dis, cfg.vmax = 1e9, 3
     log = synth.make_known_log(cfg)
     res = []
-    for rows in (0, -1):
+    for packed in (True, False):
         bt = hip.BatchEKF(B, n)
-        bt.set_tuning(rows)
+        bt.set_call_fused(False)   # the per-landmark rank-2 stream is what packs rows
+        bt.set_row_packing(packed)
         bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
         bt.run_known()
         res.append(([bt.state(b) for b in (0, B // 2, B - 1)], [bt.cov(b) for b in (0, B // 2, B - 1)], bt.checksum()))
