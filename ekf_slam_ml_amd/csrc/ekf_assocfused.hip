@@ -18,8 +18,8 @@
 
 namespace ekf {
 
-constexpr int kAssocThreads = 256;
-constexpr int kAssocSlice = 256;
+constexpr int kAssocThreads = 256;     // k_assoc_reading: four wavefronts with different roles ...
+constexpr int kAssocLandmarks = 64;    // ... around 64 landmarks (small workgroups spread the gathers over many CUs)
 
 // Scores of one reading against the M known landmarks: ONE LANDMARK PER THREAD, 64-thread workgroups spread over the
 // chip (the per-landmark chain -- two atan2, the divisions of H, S, S^-1 -- is ~800 instructions; M = 1000 takes two
@@ -60,41 +60,32 @@ __global__ __launch_bounds__(64) void k_assoc_score(PoolView pv, double mx, doub
     const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
     const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
     scores[i] = t0 * v0 + t1 * v1;
-    double* tr = terms + (size_t)i * 16;
+    // correction terms of every scored landmark, [16][n]: consecutive landmarks are consecutive addresses
+    double* tr = terms + i;
+    const size_t ts = (size_t)pv.n;
 #pragma unroll
-    for (int k = 0; k < 5; k++) { tr[k] = m.H[0][k]; tr[5 + k] = m.H[1][k]; }
-    tr[10] = Si[0][0]; tr[11] = Si[0][1]; tr[12] = Si[1][0]; tr[13] = Si[1][1];
-    tr[14] = v0; tr[15] = v1;
+    for (int k = 0; k < 5; k++) { tr[k * ts] = m.H[0][k]; tr[(5 + k) * ts] = m.H[1][k]; }
+    tr[10 * ts] = Si[0][0]; tr[11 * ts] = Si[0][1]; tr[12 * ts] = Si[1][0]; tr[13 * ts] = Si[1][1];
+    tr[14 * ts] = v0; tr[15 * ts] = v1;
 }
 
 // K(r, :) and G(:, r) of the correction the workgroup has decided on, at state index r: k_gain's arithmetic on the stored
-// covariance minus the call's pc pending pairs (sh_K5 / sh_G5: the pairs at the five indices c5(lm))
-__device__ __forceinline__ void assoc_gain_at(const double* __restrict__ Sg, const double* __restrict__ Ub,
-                                              const double* __restrict__ Vb, int ld, int r, int lm, int pc,
+// covariance minus the call's pc pending pairs.  sh_K5 / sh_G5: the pairs at the five indices c5(lm); uv[v] = the pairs'
+// own values at index r, {U[2v](r), U[2v+1](r), V[2v](r), V[2v+1](r)} (loaded by the caller long before: no memory
+// round trip inside).  p / g: Sigma(r, c5(lm)) and Sigma(c5(lm), r) as stored.
+__device__ __forceinline__ void assoc_gain_at(double (&p)[5], double (&g)[5], const double (*uv)[4], int pc,
                                               const double (*sh_K5)[5][2], const double (*sh_G5)[5][2],
                                               const double* sh_H, const double* sh_Si, double& k0, double& k1, double& g0,
                                               double& g1) {
-    double p[5], g[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int c = idx5(k, lm);
-        p[k] = Sg[(size_t)r * ld + c];   // column gather (Sigma * H^T reads columns)
-        g[k] = Sg[(size_t)c * ld + r];   // row gather    (H * Sigma reads rows)
-    }
-    // the pending factor rows of index r: pair v + 1 in flight while pair v is folded in
-    double kr0 = 0.0, kr1 = 0.0, gr0 = 0.0, gr1 = 0.0;
-    if (pc > 0) { kr0 = Ub[r]; kr1 = Ub[(size_t)ld + r]; gr0 = Vb[r]; gr1 = Vb[(size_t)ld + r]; }
-    for (int v = 0; v < pc; v++) {
-        const int vn = v + 1 < pc ? v + 1 : v;
-        const double nk0 = Ub[(size_t)(2 * vn) * ld + r], nk1 = Ub[(size_t)(2 * vn + 1) * ld + r];
-        const double ng0 = Vb[(size_t)(2 * vn) * ld + r], ng1 = Vb[(size_t)(2 * vn + 1) * ld + r];
+    for (int v = 0; v < kCallV - 1; v++)
+        if (v < pc) {   // (uniform)
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            p[k] = p[k] - (kr0 * sh_G5[v][k][0] + kr1 * sh_G5[v][k][1]);
-            g[k] = g[k] - (sh_K5[v][k][0] * gr0 + sh_K5[v][k][1] * gr1);
+            for (int k = 0; k < 5; k++) {
+                p[k] = p[k] - (uv[v][0] * sh_G5[v][k][0] + uv[v][1] * sh_G5[v][k][1]);
+                g[k] = g[k] - (sh_K5[v][k][0] * uv[v][2] + sh_K5[v][k][1] * uv[v][3]);
+            }
         }
-        kr0 = nk0; kr1 = nk1; gr0 = ng0; gr1 = ng1;
-    }
     double sht0 = 0.0, sht1 = 0.0;
     g0 = 0.0; g1 = 0.0;
 #pragma unroll
@@ -109,43 +100,51 @@ __device__ __forceinline__ void assoc_gain_at(const double* __restrict__ Sg, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// ONE launch per reading j of the call.  Every workgroup first takes the decision for reading j from the scores the
-// previous launch of the call left (a reduction over M values: cheap enough to repeat in every workgroup, unlike the
-// scoring itself), then plays one of two roles -- no workgroup waits for another:
-//   gain   (blocks < gain_blocks, a slice of 256 state indices each): K(i, :), G(:, i) of reading j's correction,
-//          appended as pair pc; state(i) += K nu, out of place (:376-385)
-//   score  (the other blocks, one landmark per thread; only when a reading j + 1 follows in this pass): the Mahalanobis
-//          scores of reading j + 1 (:300-309) against the covariance and state AS THEY WILL STAND after reading j's
-//          correction -- the thread rebuilds what it needs of pair pc itself: K and G at its landmark's two indices (the
-//          pose's three come once per workgroup), by the gain role's own function, so the values are the gain role's bit for
-//          bit -- and leaves scores and correction terms for the next launch.
+// ONE launch per reading j of the call; no workgroup waits for another.  A workgroup of four wavefronts owns 64 landmarks
+// and their 128 state indices (workgroup 0 also the pose); lane l of every wave belongs to landmark li = 64 b + l:
+//   wave A   state index 3 + 2 li: gain of reading j's correction there
+//   wave B   state index 4 + 2 li: the gain there, and the landmark's score for reading j + 1
+//   wave P   lanes 0..2: the pose indices 0..2; lane 3: the next reading in polar form, once per workgroup
+//   wave S   scans the scores of reading j for the decision (with the others' help)
+// 1. everything that does not depend on the decision is requested at once: the pending pairs' values at the owned
+//    indices, the state entries, the scores; wave B also the landmark's 5 x 5 block of Sigma
+// 2. the decision for reading j, :293-330, from the scores the previous launch left (a reduction over M values: cheap
+//    enough to repeat in every workgroup, unlike the scoring itself)
+// 3. gain: K(r, :), G(:, r) of reading j's correction at the owned index -> pair pc of the call, state(r) += K nu out of
+//    place (:376-385).  While the gathers of Sigma(r, c5) / Sigma(c5, r) are in flight, wave B brings its block up to date
+//    with the call's pending pairs.  Waves A and P publish their gains to the workgroup.
+// 4. when a reading j + 1 follows in this pass: wave B folds pair pc into its block (its own values + wave A's + the pose's)
+//    and scores the landmark (:300-309) against the covariance and state AS THEY STAND after reading j's correction; score
+//    and correction terms are left for the next launch.
 // scores / terms / association record / state ping-pong between launches (a fast workgroup of launch j never writes what
 // a slow one still reads).  Same operations in the same order as k_maha + k_assoc_decide + k_gain + k_rank2.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(PoolView pv, double mx, double my, int has_next, double mxn,
-                                                                 double myn, const AssocRec* __restrict__ assoc_in,
-                                                                 AssocRec* __restrict__ assoc_next, int* __restrict__ assoc_out_j,
-                                                                 double* __restrict__ state_out, double* __restrict__ Uall,
-                                                                 double* __restrict__ Vall, int* __restrict__ cnt_out, int pc,
-                                                                 int Nb, int zero_upto, int gain_blocks,
-                                                                 const double* __restrict__ scores, const double* __restrict__ terms,
-                                                                 double* __restrict__ scores_out, double* __restrict__ terms_out) {
+__global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
+    PoolView pv, double mx, double my, int has_next, double mxn, double myn, const AssocRec* __restrict__ assoc_in,
+    AssocRec* __restrict__ assoc_next, int* __restrict__ assoc_out_j, double* __restrict__ state_out, double* __restrict__ Uall,
+    double* __restrict__ Vall, int* __restrict__ cnt_out, int pc, int Nb, int zero_upto, int m_bound,
+    const double* __restrict__ scores, const double* __restrict__ terms, double* __restrict__ scores_out,
+    double* __restrict__ terms_out, long long* __restrict__ trace) {
     const int tid = threadIdx.x;
-    const int n = pv.n, ld = pv.ld;
+    const int n = pv.n, N = pv.N, ld = pv.ld;
+    // diagnostics (ekf_phase_trace): lane 0 of wave B of workgroup 0 stamps the 100 MHz wall clock, 16 slots per reading
+#define AR_TR(k) do { if (trace && blockIdx.x == 0 && tid == 64) trace[pc * 16 + (k)] = wall_clock64(); } while (0)
+    AR_TR(0);
     const double* __restrict__ Sg = pv.sigma;
     const double* __restrict__ st = pv.state;
-    // (the factor rows < 2 pc are read-only here; rows 2 pc, 2 pc + 1 are written by the gain role: distinct rows)
+    // (the factor rows < 2 pc are read-only here; rows 2 pc .. are written: distinct rows of the same buffers)
     const double* Ub = Uall;
     const double* Vb = Vall;
-    const bool gain_role = (int)blockIdx.x < gain_blocks;
     const bool lead = blockIdx.x == 0;
-    const int i = blockIdx.x * kAssocSlice + tid;   // gain role: state index
-    // last reading of a pass: the pair rows up to the streaming kernel's (rounded) correction count become exact no-ops
-    if (gain_role && i < ld)
-        for (int v = pc + 1; v < zero_upto; v++) {
-            Uall[(size_t)(2 * v) * ld + i] = 0.0; Uall[(size_t)(2 * v + 1) * ld + i] = 0.0;
-            Vall[(size_t)(2 * v) * ld + i] = 0.0; Vall[(size_t)(2 * v + 1) * ld + i] = 0.0;
-        }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool wA = wave == 0, wB = wave == 1, wP = wave == 2;
+    const int li = blockIdx.x * kAssocLandmarks + lane;   // waves A, B: landmark
+    // the state index this thread owns (none: -1)
+    const int r = wA ? 3 + 2 * li : wB ? 4 + 2 * li : (wP && lane < 3) ? lane : -1;
+    const bool own = r >= 0 && r < ld && (!wP || lead);   // ... and writes (the pose is written by workgroup 0 only)
+    const bool gains = r >= 0 && r < Nb;                  // ... and has a gain to build (inside the active prefix)
+    const int rl = r >= 0 && r < N ? r : 0;               // clamped for loads
+    const int ra = wB ? (3 + 2 * li < N ? 3 + 2 * li : 0) : 0;   // wave B: its partner's index (clamped)
 
     __shared__ double sh_d[kAssocThreads / 64];
     __shared__ int sh_i[kAssocThreads / 64];
@@ -153,23 +152,68 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(PoolView pv, do
     __shared__ double sh_t[2];
     __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
     __shared__ double sh_K5[kCallV][5][2], sh_G5[kCallV][5][2];   // pending pairs at {0,1,2} and at the winner's two indices
-    __shared__ double sh_Kp[3][2], sh_Gp[3][2], sh_pose[3];       // score role: pair pc and the corrected state at the pose indices
+    __shared__ double sh_Kp[3][2], sh_Gp[3][2], sh_pose[3];       // pair pc and the corrected state at the pose indices
+    __shared__ double sh_KA[kAssocLandmarks][2], sh_GA[kAssocLandmarks][2], sh_soA[kAssocLandmarks];   // ... at wave A's indices
+    __shared__ double sh_z[2];                                    // (r, phi) of the next reading, :142-146
 
+    // ---- 1. requests that do not depend on the decision ----
     const int M = assoc_in[0].known_count;
     const double theta = st[0], x = st[1], y = st[2];   // fresh pose, :219-221 / :331-333
-    if (tid < 6 * pc) {   // pose part of the pending pairs
-        const int v = tid / 6, r = (tid % 6) >> 1, h = tid & 1;
-        sh_K5[v][r][h] = Ub[(size_t)(2 * v + h) * ld + r];
-        sh_G5[v][r][h] = Vb[(size_t)(2 * v + h) * ld + r];
+    double uv[kCallV - 1][4];                           // pending pairs at the owned index
+    double ua[kCallV - 1][4];                           // wave B: ... and at its partner's (for the block update)
+#pragma unroll
+    for (int v = 0; v < kCallV - 1; v++) {
+        const int vc = v < pc ? v : 0;
+        uv[v][0] = Ub[(size_t)(2 * vc) * ld + rl]; uv[v][1] = Ub[(size_t)(2 * vc + 1) * ld + rl];
+        uv[v][2] = Vb[(size_t)(2 * vc) * ld + rl]; uv[v][3] = Vb[(size_t)(2 * vc + 1) * ld + rl];
     }
-
-    // ---- decision, :293-330, from the scores left by the previous launch (k_assoc_score for the first reading of a pass) ----
+    const double st_r = st[rl];
+    const bool scorer = wB && has_next && li < n;   // (whether li < known count after the decision is seen later)
+    double S55[5][5];
+    if (scorer) {
+#pragma unroll
+        for (int v = 0; v < kCallV - 1; v++) {
+            const int vc = v < pc ? v : 0;
+            ua[v][0] = Ub[(size_t)(2 * vc) * ld + ra]; ua[v][1] = Ub[(size_t)(2 * vc + 1) * ld + ra];
+            ua[v][2] = Vb[(size_t)(2 * vc) * ld + ra]; ua[v][3] = Vb[(size_t)(2 * vc + 1) * ld + ra];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int l = 0; l < 5; l++) S55[k][l] = Sg[(size_t)idx5(k, li) * ld + idx5(l, li)];
+    }
+    if (tid < 6 * pc) {   // pose part of the pending pairs
+        const int v = tid / 6, q = (tid % 6) >> 1, h = tid & 1;
+        sh_K5[v][q][h] = Ub[(size_t)(2 * v + h) * ld + q];
+        sh_G5[v][q][h] = Vb[(size_t)(2 * v + h) * ld + q];
+    }
     double best = pv.p.gate_new;  // :293
     int bi = INT_MAX;
-    for (int q = tid; q < M; q += kAssocThreads) {
-        const double d = scores[q];
-        if (d < best) { best = d; bi = q; }  // :305-309 (NaN never wins)
+    // the scan of the scores, every thread of the workgroup, four loads in flight per thread (m_bound >= M is the host's
+    // bound: the loads wait neither for M nor for each other)
+    for (int q0 = tid; q0 < m_bound; q0 += 4 * kAssocThreads) {
+        double d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) d[u] = scores[min(q0 + u * kAssocThreads, m_bound - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = q0 + u * kAssocThreads;
+            if (q < M && d[u] < best) { best = d[u]; bi = q; }  // :305-309 (NaN never wins)
+        }
     }
+    // last reading of a pass: the pair rows up to the streaming kernel's (rounded) correction count become exact no-ops
+    if (own)
+        for (int v = pc + 1; v < zero_upto; v++) {
+            Uall[(size_t)(2 * v) * ld + r] = 0.0; Uall[(size_t)(2 * v + 1) * ld + r] = 0.0;
+            Vall[(size_t)(2 * v) * ld + r] = 0.0; Vall[(size_t)(2 * v + 1) * ld + r] = 0.0;
+        }
+    if (wP && lane == 3 && has_next) {   // the next reading in polar form, once per workgroup
+        sh_z[0] = sqrt(mxn * mxn + myn * myn);
+        sh_z[1] = atan2(myn, mxn);
+    }
+    AR_TR(1);
+
+    // ---- 2. decision, :293-330 ----
     double rd = best;
     int ri = bi;
 #pragma unroll
@@ -178,8 +222,9 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(PoolView pv, do
         const int oi = __shfl_down(ri, off, kWave);
         if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
     }
-    if ((tid & 63) == 0) { sh_d[tid >> 6] = rd; sh_i[tid >> 6] = ri; }
+    if (lane == 0) { sh_d[wave] = rd; sh_i[wave] = ri; }
     __syncthreads();
+    AR_TR(2);
     if (tid == 0) {
         for (int w = 1; w < kAssocThreads / 64; w++)
             if (sh_d[w] < rd || (sh_d[w] == rd && sh_i[w] < ri)) { rd = sh_d[w]; ri = sh_i[w]; }
@@ -211,39 +256,88 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(PoolView pv, do
         }
     }
     __syncthreads();
+    AR_TR(3);
     const int lm = sh_lm;
     const int is_new = sh_new;
     const int Mn = sh_Mn;
+    const bool corr = lm >= 0;   // (uniform) reading j appends a non-zero pair
     double* Uw = Uall + (size_t)(2 * pc) * ld;
     double* Vw = Vall + (size_t)(2 * pc) * ld;
-    if (lm >= 0) {   // (uniform)
-        // pending pairs at the winner's two indices; the winner's terms (from the thread that scored it, or built for a new one)
+
+    // the landmark's block as it stands NOW, for the next reading's score: minus the pending pairs of the call, in order
+    // (wave B; the pose values of the pairs are read straight from the factor rows: wave-uniform addresses).  Placed
+    // behind the requests of step 3 so that it runs while they are in flight.
+    auto pending_block = [&]() {
+        if (scorer) {
+#pragma unroll
+            for (int v = 0; v < kCallV - 1; v++)
+                if (v < pc) {   // (uniform)
+                    double kr[5][2], gc[5][2];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        kr[k][0] = Ub[(size_t)(2 * v) * ld + k]; kr[k][1] = Ub[(size_t)(2 * v + 1) * ld + k];
+                        gc[k][0] = Vb[(size_t)(2 * v) * ld + k]; gc[k][1] = Vb[(size_t)(2 * v + 1) * ld + k];
+                    }
+                    kr[3][0] = ua[v][0]; kr[3][1] = ua[v][1]; gc[3][0] = ua[v][2]; gc[3][1] = ua[v][3];
+                    kr[4][0] = uv[v][0]; kr[4][1] = uv[v][1]; gc[4][0] = uv[v][2]; gc[4][1] = uv[v][3];
+#pragma unroll
+                    for (int k = 0; k < 5; k++)
+#pragma unroll
+                        for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
+                }
+        }
+    };
+
+    // ---- 3. gain: pair pc and the state at the owned index ----
+    double k0 = 0.0, k1 = 0.0, g0 = 0.0, g1 = 0.0;
+    double so = r >= 0 && r < N ? st_r : 0.0;
+    if (corr) {   // (uniform)
+        // Sigma(r, c5(lm)) and Sigma(c5(lm), r): requested before anything else waits
+        double p[5], g[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int c = idx5(k, lm);
+            p[k] = Sg[(size_t)rl * ld + c];   // column gather (Sigma * H^T reads columns)
+            g[k] = Sg[(size_t)c * ld + rl];   // row gather    (H * Sigma reads rows)
+        }
+        // pending pairs at the winner's two indices; the winner's terms (from the thread that scored it, or built for a new
+        // one): requested into registers, stored to LDS behind the block update, which runs while they are in flight
+        double wk = 0.0, wg = 0.0, tv = 0.0;
         if (tid < 4 * pc) {
             const int v = tid >> 2, q = (tid >> 1) & 1, h = tid & 1;
-            sh_K5[v][3 + q][h] = Ub[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
-            sh_G5[v][3 + q][h] = Vb[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
+            wk = Ub[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
+            wg = Vb[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
         }
-        if (!is_new && tid >= 64 && tid < 80) {   // the winner's terms as the scoring launch left them
-            const int q = tid - 64;
-            const double tv = terms[(size_t)lm * 16 + q];
+        if (!is_new && wP && lane >= 16 && lane < 32) tv = terms[(size_t)(lane - 16) * n + lm];   // as the scoring launch left them
+        AR_TR(4);
+        pending_block();
+        AR_TR(5);
+        if (tid < 4 * pc) {
+            const int v = tid >> 2, q = (tid >> 1) & 1, h = tid & 1;
+            sh_K5[v][3 + q][h] = wk;
+            sh_G5[v][3 + q][h] = wg;
+        }
+        if (!is_new && wP && lane >= 16 && lane < 32) {
+            const int q = lane - 16;
             if (q < 10) sh_H[q] = tv;
             else if (q < 14) sh_Si[q - 10] = tv;
             else if (q == 14) sh_nu[0] = tv;
             else sh_nu[1] = normalize_angle(tv);   // :183 (the score used it unwrapped)
         }
         __syncthreads();
+        AR_TR(6);
         if (is_new) {   // (uniform)
             if (tid == 0) {   // :331-381 with the fresh pose: a new landmark has no score record
                 MeasTerms m;
                 measurement_terms(sh_t[0], sh_t[1], mx, my, theta, x, y, m);
-                double S55[5][5], S[2][2], Si[2][2];
+                double B55[5][5], S[2][2], Si[2][2];
                 for (int k = 0; k < 5; k++)
                     for (int l = 0; l < 5; l++) {
                         double xe = Sg[(size_t)idx5(k, lm) * ld + idx5(l, lm)];
                         for (int v = 0; v < pc; v++) xe = xe - (sh_K5[v][k][0] * sh_G5[v][l][0] + sh_K5[v][k][1] * sh_G5[v][l][1]);
-                        S55[k][l] = xe;
+                        B55[k][l] = xe;
                     }
-                innovation_cov(S55, m.H, pv.p.r_meas, S);
+                innovation_cov(B55, m.H, pv.p.r_meas, S);
                 inv2(S, Si);
                 for (int k = 0; k < 5; k++) { sh_H[k] = m.H[0][k]; sh_H[5 + k] = m.H[1][k]; }
                 sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
@@ -252,103 +346,64 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(PoolView pv, do
             }
             __syncthreads();
         }
+        if (gains) {
+            assoc_gain_at(p, g, uv, pc, sh_K5, sh_G5, sh_H, sh_Si, k0, k1, g0, g1);
+            // corrected state (:384-385); base: the stored state, or the position this reading has just initialised (:321-322)
+            double base = st_r;
+            if (is_new && r == 2 * lm + 3) base = sh_t[0];
+            if (is_new && r == 2 * lm + 4) base = sh_t[1];
+            so = base + (k0 * sh_nu[0] + k1 * sh_nu[1]);
+            if (r == 0) so = normalize_angle(so);
+        }
+    } else {
+        pending_block();
     }
-    // corrected state at index r (:384-385); base: the stored state, or the position this reading has just initialised (:321-322)
-    auto state_after = [&](int r, double k0, double k1) {
-        double base = st[r];
-        if (is_new && r == 2 * lm + 3) base = sh_t[0];
-        if (is_new && r == 2 * lm + 4) base = sh_t[1];
-        double so = base + (k0 * sh_nu[0] + k1 * sh_nu[1]);
-        if (r == 0) so = normalize_angle(so);
-        return so;
-    };
+    AR_TR(7);
+    // (dropped reading: a zero pair keeps the call's pair index = reading index; the state is carried over.  A landmark
+    // initialised by a reading that is then dropped cannot occur: a new landmark gets best = 0)
+    if (own) {
+        Uw[r] = k0; Uw[ld + r] = k1; Vw[r] = g0; Vw[ld + r] = g1;
+        state_out[r] = so;
+    }
+    if (!has_next) return;   // (uniform)
 
-    if (gain_role) {
-        if (i >= ld) return;
-        if (lm < 0) {   // dropped (uniform): a zero pair keeps the call's pair index = reading index; the state is carried over
-            Uw[i] = 0.0; Uw[ld + i] = 0.0; Vw[i] = 0.0; Vw[ld + i] = 0.0;
-            state_out[i] = st[i];
-            // (a landmark initialised by a reading that is then dropped cannot occur: a new landmark gets best = 0)
-            return;
-        }
-        // ---- K = Sigma H^T S^-1 (:376), G = H Sigma over the prefix; pair pc; state ----
-        double k0 = 0.0, k1 = 0.0, g0 = 0.0, g1 = 0.0, so = i < pv.N ? st[i] : 0.0;
-        if (i < Nb) {
-            assoc_gain_at(Sg, Ub, Vb, ld, i, lm, pc, sh_K5, sh_G5, sh_H, sh_Si, k0, k1, g0, g1);
-            so = state_after(i, k0, k1);
-        }
-        Uw[i] = k0; Uw[ld + i] = k1; Vw[i] = g0; Vw[ld + i] = g1;
-        state_out[i] = so;
-        return;
-    }
-
-    // ---- score role: reading j + 1 against the filter as it stands after reading j ----
-    if (!has_next) return;
-    const bool corr = lm >= 0;   // (uniform) reading j appends a non-zero pair
-    if (tid < 3) {               // pair pc and the corrected state at the pose indices: once per workgroup
-        double k0 = 0.0, k1 = 0.0, g0 = 0.0, g1 = 0.0, so = st[tid];
-        if (corr) {
-            assoc_gain_at(Sg, Ub, Vb, ld, tid, lm, pc, sh_K5, sh_G5, sh_H, sh_Si, k0, k1, g0, g1);
-            so = state_after(tid, k0, k1);
-        }
-        sh_Kp[tid][0] = k0; sh_Kp[tid][1] = k1; sh_Gp[tid][0] = g0; sh_Gp[tid][1] = g1;
-        sh_pose[tid] = so;
-    }
+    // ---- 4. score of reading j + 1 against the filter as it stands after reading j ----
+    if (wA) { sh_KA[lane][0] = k0; sh_KA[lane][1] = k1; sh_GA[lane][0] = g0; sh_GA[lane][1] = g1; sh_soA[lane] = so; }
+    if (wP && lane < 3) { sh_Kp[lane][0] = k0; sh_Kp[lane][1] = k1; sh_Gp[lane][0] = g0; sh_Gp[lane][1] = g1; sh_pose[lane] = so; }
     __syncthreads();
-    const int li = (blockIdx.x - gain_blocks) * kAssocThreads + tid;   // landmark scored by this thread
-    if (li >= Mn || li >= n) return;
-    // pair pc and the corrected position at the landmark's two indices
-    double kq[5][2], gq[5][2], pos[2];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { kq[k][0] = sh_Kp[k][0]; kq[k][1] = sh_Kp[k][1]; gq[k][0] = sh_Gp[k][0]; gq[k][1] = sh_Gp[k][1]; }
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int r = 3 + 2 * li + q;
-        double k0 = 0.0, k1 = 0.0, g0 = 0.0, g1 = 0.0, so = st[r];
-        if (corr) {
-            assoc_gain_at(Sg, Ub, Vb, ld, r, lm, pc, sh_K5, sh_G5, sh_H, sh_Si, k0, k1, g0, g1);
-            so = state_after(r, k0, k1);
-        }
-        kq[3 + q][0] = k0; kq[3 + q][1] = k1; gq[3 + q][0] = g0; gq[3 + q][1] = g1;
-        pos[q] = so;
-    }
-    MeasTerms m;
-    measurement_terms(pos[0], pos[1], mxn, myn, sh_pose[0], sh_pose[1], sh_pose[2], m);   // fresh pose, :219-221
-    double S55[5][5], S[2][2], Si[2][2];
-#pragma unroll
-    for (int k = 0; k < 5; k++)
-#pragma unroll
-        for (int l = 0; l < 5; l++) S55[k][l] = Sg[(size_t)idx5(k, li) * ld + idx5(l, li)];
-    for (int v = 0; v < pc; v++) {   // ... as they stand NOW: minus the pending pairs of the call, in order
+    AR_TR(8);
+    if (!scorer || li >= Mn) return;
+    if (corr) {   // ... minus reading j's own pair
         double kr[5][2], gc[5][2];
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int c = idx5(k, li);
-            kr[k][0] = Ub[(size_t)(2 * v) * ld + c]; kr[k][1] = Ub[(size_t)(2 * v + 1) * ld + c];
-            gc[k][0] = Vb[(size_t)(2 * v) * ld + c]; gc[k][1] = Vb[(size_t)(2 * v + 1) * ld + c];
-        }
+        for (int k = 0; k < 3; k++) { kr[k][0] = sh_Kp[k][0]; kr[k][1] = sh_Kp[k][1]; gc[k][0] = sh_Gp[k][0]; gc[k][1] = sh_Gp[k][1]; }
+        kr[3][0] = sh_KA[lane][0]; kr[3][1] = sh_KA[lane][1]; gc[3][0] = sh_GA[lane][0]; gc[3][1] = sh_GA[lane][1];
+        kr[4][0] = k0; kr[4][1] = k1; gc[4][0] = g0; gc[4][1] = g1;
 #pragma unroll
         for (int k = 0; k < 5; k++)
 #pragma unroll
             for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
     }
-    if (corr) {   // ... and minus reading j's own pair
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-#pragma unroll
-            for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kq[k][0] * gq[l][0] + kq[k][1] * gq[l][1]);
-    }
+    AR_TR(9);
+    MeasTerms m;
+    m.z0 = sh_z[0]; m.z1 = sh_z[1];
+    predicted_terms(sh_soA[lane], so, sh_pose[0], sh_pose[1], sh_pose[2], m);   // fresh pose, :219-221
+    AR_TR(10);
+    double S[2][2], Si[2][2];
     innovation_cov(S55, m.H, pv.p.r_meas, S);   // sums in the order of k_maha's shuffle folds
     inv2(S, Si);
     const double v0 = m.z0 - m.zh0, v1 = m.z1 - m.zh1;   // bearing NOT wrapped, :269
     const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
     const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
     scores_out[li] = t0 * v0 + t1 * v1;
-    double* tr = terms_out + (size_t)li * 16;
+    double* tr = terms_out + li;   // [16][n]
+    const size_t ts = (size_t)n;
 #pragma unroll
-    for (int k = 0; k < 5; k++) { tr[k] = m.H[0][k]; tr[5 + k] = m.H[1][k]; }
-    tr[10] = Si[0][0]; tr[11] = Si[0][1]; tr[12] = Si[1][0]; tr[13] = Si[1][1];
-    tr[14] = v0; tr[15] = v1;
+    for (int k = 0; k < 5; k++) { tr[k * ts] = m.H[0][k]; tr[(5 + k) * ts] = m.H[1][k]; }
+    tr[10 * ts] = Si[0][0]; tr[11 * ts] = Si[0][1]; tr[12 * ts] = Si[1][0]; tr[13 * ts] = Si[1][1];
+    tr[14 * ts] = v0; tr[15 * ts] = v1;
+    AR_TR(11);
+#undef AR_TR
 }
 
 void launch_assoc_score(const PoolView& pv, double mx, double my, const AssocRec* assoc_in, const double* U, const double* V,
@@ -359,13 +414,12 @@ void launch_assoc_score(const PoolView& pv, double mx, double my, const AssocRec
 
 void launch_assoc_reading(const PoolView& pv, double mx, double my, int has_next, double mxn, double myn,
                           const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j, double* state_out, double* U,
-                          double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound_next, const double* scores,
-                          const double* terms, double* scores_out, double* terms_out, hipStream_t s) {
-    const int gain_blocks = (pv.ld + kAssocSlice - 1) / kAssocSlice;
-    const int score_blocks = has_next ? (m_bound_next + kAssocThreads - 1) / kAssocThreads : 0;
-    hipLaunchKernelGGL(k_assoc_reading, dim3(gain_blocks + score_blocks), dim3(kAssocThreads), 0, s, pv, mx, my, has_next, mxn,
-                       myn, assoc_in, assoc_next, assoc_out_j, state_out, U, V, cnt_out, pc, Nb, zero_upto, gain_blocks, scores,
-                       terms, scores_out, terms_out);
+                          double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound, const double* scores,
+                          const double* terms, double* scores_out, double* terms_out, hipStream_t s, long long* trace) {
+    const int landmarks = (pv.ld - 3 + 1) / 2;   // owners of every index of the padded row beyond the pose
+    hipLaunchKernelGGL(k_assoc_reading, dim3((landmarks + kAssocLandmarks - 1) / kAssocLandmarks), dim3(kAssocThreads),
+                       0, s, pv, mx, my, has_next, mxn, myn, assoc_in, assoc_next, assoc_out_j, state_out, U, V, cnt_out, pc, Nb,
+                       zero_upto, m_bound, scores, terms, scores_out, terms_out, trace);
 }
 
 }  // namespace ekf

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
     __shared__ double sh_pr[8];                          // folded prediction: a10, a20, u0, u1, u2
 
     CF_TR(0, 0); CF_TR(1, 0);
+    if (src.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) src.trace[61] = __builtin_amdgcn_s_memtime();   // shader clock
     // ---- which corrections: [v0, v0 + vcount) of this filter's call ----
     if (tid < kCallV) {
         int lm = -1;
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
         }
     }
     CF_TR(0, 60); CF_TR(1, 60);
+    if (src.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) src.trace[62] = __builtin_amdgcn_s_memtime();
     if (slice && i < ld) {
         so[i] = live ? st_i : 0.0;
         for (int v = cnt; v < zero_upto; v++) {   // rows of the pass this filter does not use: exact no-ops for k_rank2v

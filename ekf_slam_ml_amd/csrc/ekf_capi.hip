@@ -189,6 +189,16 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     return checked_launch();
 }
 
+// smallest active dimension for which data_association() of a single filter takes the once-per-call form (measured:
+// tools/assoc_bench.py); EKF_ASSOC_MIN_DIM overrides it for that measurement
+static int assoc_call_fused_min_dim() {
+    static const int v = [] {
+        const char* e = std::getenv("EKF_ASSOC_MIN_DIM");
+        return e ? std::atoi(e) : 1400;
+    }();
+    return v;
+}
+
 // Tail of every data_association() form: one synchronising read-back of the association record and the
 // decisions, then the caller's known_list (:323) and the host-side bounds are brought up to date.
 static ekf_status associate_finish(Pool& P, int known_count, int J, uint8_t* known, int* assoc_out) {
@@ -285,7 +295,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     // readings) -- ekf_assocfused.hip; bit-identical.  Measured at n = 1000, known = 1000 (tools/assoc_bench.py):
     // 24.5 us per reading against 26.6 us for scores + one streaming launch per reading; below that size the streaming
     // launch is cheap and two launches per reading win (configs[2]'s discovery run: 12.7 k vs 10.5 k steps/s).
-    if (!delayed && P.pv.B == 1 && P.call_fused_ok() && active_dim(0) >= 1400) {
+    if (!delayed && P.pv.B == 1 && P.call_fused_ok() && active_dim(0) >= assoc_call_fused_min_dim()) {
         EKFC(P.ensure_callfused());
         if (!P.terms) EKFC(P.dalloc(&P.terms, (size_t)(n > 0 ? n : 1) * 16));
         if (!P.terms2) {
@@ -309,8 +319,8 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
                 ekf::launch_assoc_reading(P.pv, meas_xy[2 * j], meas_xy[2 * j + 1], has_next, has_next ? meas_xy[2 * j + 2] : 0.0,
                                           has_next ? meas_xy[2 * j + 3] : 0.0, P.pv.assoc, P.assoc_alt, P.assoc_out_dev + j,
                                           P.cf_state, P.cf_U, P.cf_V, P.cf_cnt, jj, active_dim(j),
-                                          jj == jc - 1 ? ekf::rank2v_round_count(jc) : 0, m_bound(j + 1), sc_in, tm_in, sc_out,
-                                          tm_out, P.stream);
+                                          jj == jc - 1 ? ekf::rank2v_round_count(jc) : 0, m_bound(j), sc_in, tm_in, sc_out, tm_out,
+                                          P.stream, P.phase_trace);
                 EKFC(P.prof_end());
                 std::swap(P.pv.state, P.cf_state);
                 std::swap(P.pv.assoc, P.assoc_alt);

@@ -168,10 +168,12 @@ __device__ __forceinline__ void predicted_terms(double tx, double ty, double the
     m.zh0 = sqrt(d);
     m.zh1 = normalize_angle(atan2(delta_y, delta_x) - theta);
     double sd = sqrt(d);
-    m.H[0][0] = 0;  m.H[0][1] = -delta_x / sd; m.H[0][2] = -delta_y / sd;
-    m.H[1][0] = -1; m.H[1][1] = delta_y / d;   m.H[1][2] = -delta_x / d;
-    m.H[0][3] = delta_x / sd; m.H[0][4] = delta_y / sd;
-    m.H[1][3] = -delta_y / d; m.H[1][4] = delta_x / d;
+    // eight quotients, four divisions: (-a) / b == -(a / b) bit for bit in IEEE arithmetic (the sign is an exclusive or)
+    const double xs = delta_x / sd, ys = delta_y / sd, yd = delta_y / d, xd = delta_x / d;
+    m.H[0][0] = 0;  m.H[0][1] = -xs; m.H[0][2] = -ys;
+    m.H[1][0] = -1; m.H[1][1] = yd;  m.H[1][2] = -xd;
+    m.H[0][3] = xs;  m.H[0][4] = ys;
+    m.H[1][3] = -yd; m.H[1][4] = xd;
 }
 
 // S = H Sigma H^T + R on the 5x5 sub-block, same summation order as the CPU restatement.
@@ -454,15 +456,16 @@ void launch_rank2v(const PoolView& pv, const double* U, const double* V, const i
 // data_association() of a single filter with Sigma streamed once per call (ekf_assocfused.hip; readings travel by value).
 // launch_assoc_score: scores + correction terms of the FIRST reading of a pass against the stored covariance minus the pc
 // pending pairs.  launch_assoc_reading: reading (mx, my) -- decision from `scores` / `terms`, gain -> pair pc, state out of
-// place -- and, when has_next, the scores / terms of the next reading (mxn, myn) into scores_out / terms_out (m_bound_next:
-// host bound of the known count after this reading).  Nb: active dimension of the reading (discovered prefix).  The caller
+// place -- and, when has_next, the scores / terms of the next reading (mxn, myn) into scores_out / terms_out (terms: [16][n]).
+// m_bound: host bound of the known count in front of the reading.  Nb: active dimension of the reading (discovered prefix).  The caller
 // ends the pass with launch_rank2v.
 void launch_assoc_score(const PoolView& pv, double mx, double my, const AssocRec* assoc_in, const double* U, const double* V,
                         int pc, int m_bound, double* scores, double* terms, hipStream_t s);
 void launch_assoc_reading(const PoolView& pv, double mx, double my, int has_next, double mxn, double myn,
                           const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j, double* state_out, double* U,
-                          double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound_next, const double* scores,
-                          const double* terms, double* scores_out, double* terms_out, hipStream_t s);
+                          double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound, const double* scores,
+                          const double* terms, double* scores_out, double* terms_out, hipStream_t s,
+                          long long* trace = nullptr);
 int rank2v_round_count(int vcount);   // corrections per pass, rounded up to an instantiated count of k_rank2v
 
 // one step of an unknown-association log for every filter of a pool in ONE launch, any prefix size (ekf_stepfused.hip):

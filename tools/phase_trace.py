@@ -18,12 +18,14 @@ for t in range(60):
     f.prediction(log.twist[t, 0]); f.measurement(*inputs[t])
 f.phase_trace(True)
 by_v = {}
+clk = []
 for t in range(60, steps):
     V = int(inputs[t][1].sum())
     f.prediction(log.twist[t, 0]); f.measurement(*inputs[t])
     tr = f.phase_trace(True, fetch=True).astype(np.float64)
     if V == 0 or V > 8 or tr[0, 0] == 0:
         continue
+    clk.append((tr[0, 62] - tr[0, 61]) / max(tr[0, 60] - tr[0, 0], 1.0) * 100.0)   # shader cycles per 10-ns tick -> MHz
     by_v.setdefault(V, []).append((tr - tr[0, 0]) / 100.0)   # us
 f.phase_trace(False)
 for V in sorted(by_v):
@@ -35,6 +37,7 @@ for V in sorted(by_v):
         s = a[1, 3 + 5 * t: 5 + 5 * t]
         print(f"   correction {t}: barrier A {c[0]:.2f}  terms_h(t+1) done {c[1]:.2f}  barrier B {c[2]:.2f}  S, S^-1, gains(t+1) done {c[3]:.2f}"
               f" | slice: barrier A {s[0]:.2f}  panels done {s[1]:.2f}")
+print(f"in-kernel shader clock (median over calls): {np.median(clk):.0f} MHz")
 # wall time per tick with the trace off
 f.sync()
 t0 = time.perf_counter()
