@@ -16,7 +16,7 @@
 // of Sigma, and every other element then takes its V rank-2 updates in ONE read-modify-write:
 //       x <- ((x - (K_0[r].G_0[c])) - (K_1[r].G_1[c])) - ...      -- the very sequence the per-landmark path applies.
 //
-// k_call_factors  grid (column/row slices of 256, filters).  Wave 0 of every workgroup runs the core filter (the
+// k_call_factors  grid (column/row slices of 256, filters).  Waves 0-2 of every workgroup run the core filter (the
 //                 transcendental chain, lane-parallel: wave_terms) one correction AHEAD of the other waves (wave 1 updates the
 //                 core block, the slice waves carry one panel column and one panel row per thread in registers and emit the
 //                 factors U = K, Vf = G); the chain's loop is rolled so that its code stays in the instruction cache.
@@ -46,15 +46,17 @@ __device__ __forceinline__ constexpr int core5(int k, int v) { return k < 3 ? k 
 // diagnostics: stamp slot k of row `who` (0: lane 0 of the control wave, 1: lane 0 of the first slice wave)
 #define CF_TR(who, k)                                                                                              \
     do {                                                                                                           \
-        if (src.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 128 * (who) && (k) < kTraceSlots)         \
+        if (src.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == kCtl * (who) && (k) < kTraceSlots)        \
             src.trace[(who) * kTraceSlots + (k)] = wall_clock64();                                                \
     } while (0)
 
+constexpr int kCtl = 192;   // control threads: wave 0 geometry / S / gains, wave 1 angles, wave 2 the core block's update
+
 template <int SLICE>
-__global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallSrc src, double* __restrict__ Uall,
+__global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, CallSrc src, double* __restrict__ Uall,
                                                                  double* __restrict__ Vall, int* __restrict__ cnt_out,
                                                                  double* __restrict__ state_out, int zero_upto) {
-    constexpr int kFactorThreads = 128 + SLICE;   // wave 0: the core filter's terms and gains; wave 1: the core block update
+    constexpr int kFactorThreads = kCtl + SLICE;
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int N = pv.N, ld = pv.ld;
     const double* __restrict__ Sg = pv.sigma + (size_t)b * pv.sigma_stride;
@@ -105,17 +107,89 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
         sh_cidx[4 + 2 * tid] = lm >= 0 ? 4 + 2 * lm : 0;
         if (tid < 3) sh_cidx[tid] = tid;
     }
-    // the pose every correction of the call uses, captured ONCE (:109-111): the load flies with the gathers below
-    double pose_k = 0.0;
-    if (tid >= 64 && tid < 67) pose_k = src.fresh_pose ? st[tid - 64] : pv.snap[(size_t)b * 4 + tid - 64];
-    // a folded prediction(): its sines and cosines only need theta -- lanes 0 / 1 of the last slice wave evaluate
-    // sin and cos of theta and theta + dtheta (two calls deep instead of four) while the gathers are in flight
-    if (src.has_twist && tid >= kFactorThreads - 64) {
-        const double th = st[0];
-        const double arg = (lane & 1) ? th + src.dtheta : th;
-        const double sv = sin(arg), cv = cos(arg);
-        const double sin_t = lane_bcast(sv, 0), sin_td = lane_bcast(sv, 1), cos_t = lane_bcast(cv, 0), cos_td = lane_bcast(cv, 1);
-        if (lane == 0) {
+    // The landmark list.  SRC_INLINE: it sits in the kernel arguments, so every wave has it (and the addresses of all its
+    // gathers) at once, without a barrier in front of the loads; the other modes read it from memory through LDS.
+    // Landmarks are listed in ascending order and -1 padded: the count is the leading run.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lmr[kCallV];
+    int cnt = 0;
+    if (src.mode == SRC_INLINE) {   // (uniform)
+        bool run = true;
+#pragma unroll
+        for (int v = 0; v < kCallV; v++) {
+            int lm = v < src.vcount ? src.inl_lm[v] : -1;
+            if (lm >= pv.n) lm = -1;
+            run = run && lm >= 0;
+            if (run) cnt++;
+            lmr[v] = run ? lm : 0;
+        }
+    } else {
+        __syncthreads();
+        const unsigned long long miss = __ballot(lane >= kCallV || sh_lm[lane < kCallV ? lane : 0] < 0);
+        cnt = __builtin_ctzll(miss | (1ull << kCallV));
+#pragma unroll
+        for (int v = 0; v < kCallV; v++) lmr[v] = v < cnt ? sh_lm[v] : 0;
+    }
+    const int Nc = 3 + 2 * cnt;
+    auto cidx = [&](int j) {   // global index of core position j (clamped to a valid one beyond Nc); j compile-time below
+        return j < 3 ? j : 3 + 2 * lmr[(j - 3) >> 1] + ((j - 3) & 1);
+    };
+
+    // ---- requests: every wave issues its loads now; nothing below waits for another wave until barrier P1 ----
+    const int s = tid - kCtl;
+    const int i = blockIdx.x * SLICE + s;
+    const bool slice = tid >= kCtl;
+    const bool w0 = tid < 64;
+    const bool live = slice && i < N;
+    double Rcol[kNcMax], Crow[kNcMax], st_i = 0.0;
+    if (slice) {
+        // panels: slice thread s carries column i of Sigma[C, :] and row i of Sigma[:, C], i = slice base + s
+        const int ic = live ? i : 0;
+#pragma unroll
+        for (int j = 0; j < kNcMax; j++) {   // unconditional, clamped: 2 x 19 loads in flight, one round trip
+            const int cj = cidx(j);
+            Rcol[j] = Sg[(size_t)cj * ld + ic];   // coalesced across the slice
+            Crow[j] = Sg[(size_t)ic * ld + cj];   // one or two sectors of row i per landmark
+        }
+        st_i = st[ic];
+#pragma unroll
+        for (int j = 0; j < kNcMax; j++)
+            if (!live || j >= Nc) { Rcol[j] = 0.0; Crow[j] = 0.0; }
+        if (!live) st_i = 0.0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kNcMax; j++) { Rcol[j] = 0.0; Crow[j] = 0.0; }
+    }
+    if (wave == 0) {
+        // ---- core block and core state: lane = (row group, column), all gathers issued before the first store.  (sh_cidx
+        // was written by lanes of this very wave: DS instructions of a wave execute in order) ----
+        wave_sync_lds();
+        constexpr int kRounds = (kNcMax * kNcMax + 63) / 64;
+        double cbv[kRounds];
+#pragma unroll
+        for (int q = 0; q < kRounds; q++) {
+            const int e = lane + 64 * q;
+            const int j = min(e / kNcMax, kNcMax - 1), c = e - (e / kNcMax) * kNcMax;   // compile-time divisor
+            cbv[q] = Sg[(size_t)sh_cidx[j] * ld + sh_cidx[c]];   // positions beyond Nc are clamped copies, never used
+        }
+        const double scv = st[sh_cidx[lane < kNcMax ? lane : 0]];
+#pragma unroll
+        for (int q = 0; q < kRounds; q++) {
+            const int e = lane + 64 * q;
+            if (e < kNcMax * kNcMax) sh_Cb[e / kNcMax][e % kNcMax] = cbv[q];
+        }
+        if (lane < kNcMax) sh_sc[lane] = scv;
+    } else if (wave == 1) {
+        // the pose every correction of the call uses, captured ONCE (:109-111) -- with a folded prediction() the PREDICTED
+        // pose (theta is not wrapped, :99).  Its sines and cosines only need theta: lanes 0 / 1 evaluate sin and cos of
+        // theta and theta + dtheta (two calls deep instead of four) while the other waves' gathers are in flight.
+        double pose_k = 0.0;
+        if (lane < 3) pose_k = src.fresh_pose ? st[lane] : pv.snap[(size_t)b * 4 + lane];
+        if (src.has_twist) {   // (uniform)
+            const double th = st[0];
+            const double arg = (lane & 1) ? th + src.dtheta : th;
+            const double sv = sin(arg), cv = cos(arg);
+            const double sin_t = lane_bcast(sv, 0), sin_td = lane_bcast(sv, 1), cos_t = lane_bcast(cv, 0), cos_td = lane_bcast(cv, 1);
             const double dtheta = src.dtheta, dx = src.dx;
             double u0, u1, u2, a10, a20;
             if (fabs(dtheta) < pv.p.straight_eps) {  // :79-86
@@ -131,18 +205,25 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
                 a10 = -(dx / dtheta) * cos_t + (dx / dtheta) * cos_td;
                 a20 = -(dx / dtheta) * sin_t + (dx / dtheta) * sin_td;
             }
-            sh_pr[0] = a10; sh_pr[1] = a20; sh_pr[2] = u0; sh_pr[3] = u1; sh_pr[4] = u2;
-            if (blockIdx.x == 0) { src.pred_out[(size_t)b * 2] = a10; src.pred_out[(size_t)b * 2 + 1] = a20; }
+            if (lane == 0) {
+                sh_pr[0] = a10; sh_pr[1] = a20; sh_pr[2] = u0; sh_pr[3] = u1; sh_pr[4] = u2;
+                if (blockIdx.x == 0) { src.pred_out[(size_t)b * 2] = a10; src.pred_out[(size_t)b * 2 + 1] = a20; }
+            }
+            pose_k = pose_k + (lane == 0 ? u0 : lane == 1 ? u1 : u2);
         }
+        if (lane < 3) {
+            sh_pose[lane] = pose_k;
+            if (blockIdx.x == 0 && src.fresh_pose) pv.snap[(size_t)b * 4 + lane] = pose_k;
+        }
+    } else if (wave == 2) {
+        // factors of unused core rows are exact zeros (the slices run their loops to kNcMax)
+        for (int e = lane; e < kCallV * kNcMax; e += 64) { sh_Kc[e / kNcMax][e % kNcMax][0] = 0.0; sh_Kc[e / kNcMax][e % kNcMax][1] = 0.0; }
+        for (int e = lane; e < kCallV * (kNcMax + 1); e += 64) { sh_Gc[e / (kNcMax + 1)][0][e % (kNcMax + 1)] = 0.0; sh_Gc[e / (kNcMax + 1)][1][e % (kNcMax + 1)] = 0.0; }
     }
-    __syncthreads();
-    // landmarks are listed in ascending order and -1 padded: the count is the leading run.  Every wavefront derives it
-    // by itself from the list (one ballot): no second barrier, no serial scan on the critical path.
-    const unsigned long long miss = __ballot(lane >= kCallV || sh_lm[lane < kCallV ? lane : 0] < 0);
-    const int cnt = __builtin_ctzll(miss | (1ull << kCallV));
-    const int Nc = 3 + 2 * cnt;
-    // bookkeeping (count for the streaming pass, pose record, correction record, touched set): the lanes of the LAST slice
-    // wave, in parallel, off the control wave's critical path
+    CF_TR(0, 1); CF_TR(1, 1);
+    __syncthreads();   // P1: block, core state, pose, prediction terms and the landmark list are in LDS
+    // bookkeeping (count for the streaming pass, correction record, touched set): the lanes of the LAST slice wave, in
+    // parallel, off the control waves' critical path
     if (blockIdx.x == 0 && tid >= kFactorThreads - 64) {
         if (lane == 8) cnt_out[b] = cnt;
         if (lane == 10) {
@@ -160,71 +241,19 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
             }
         }
     }
-    // global index of core position j (clamped to a valid one beyond Nc): the landmark list goes to registers first, so
-    // that every gather below has its address without a dependent LDS round trip and all of them are in flight together
-    int lmr[kCallV];
-#pragma unroll
-    for (int v = 0; v < kCallV; v++) lmr[v] = v < cnt ? sh_lm[v] : 0;
-    auto cidx = [&](int j) {   // j compile-time in the unrolled loops below
-        return j < 3 ? j : 3 + 2 * lmr[(j - 3) >> 1] + ((j - 3) & 1);
+    const double theta = sh_pose[0], x = sh_pose[1], y = sh_pose[2];
+    auto terms_geo = [&](int v) {
+        wave_terms_geo(lane, sh_sc[3 + 2 * v], sh_sc[4 + 2 * v], sh_zs[v][0], sh_zs[v][1], x, y, &sh_tv[v][0], &sh_tv[v][14]);
     };
-
-    // ---- panels: slice thread s carries column i of Sigma[C, :] and row i of Sigma[:, C], i = slice base + s ----
-    const int s = tid - 128;
-    const int i = blockIdx.x * SLICE + s;
-    const bool slice = tid >= 128;
-    const bool w0 = tid < 64, w1 = tid >= 64 && tid < 128;
-    const bool live = slice && i < N;
-    double Rcol[kNcMax], Crow[kNcMax], st_i = 0.0;
-    if (slice) {
-        const int ic = live ? i : 0;
-#pragma unroll
-        for (int j = 0; j < kNcMax; j++) {   // unconditional, clamped: 2 x 19 loads in flight, one round trip
-            const int cj = cidx(j);
-            Rcol[j] = Sg[(size_t)cj * ld + ic];   // coalesced across the slice
-            Crow[j] = Sg[(size_t)ic * ld + cj];   // one or two sectors of row i per landmark
-        }
-        st_i = st[ic];
-#pragma unroll
-        for (int j = 0; j < kNcMax; j++)
-            if (!live || j >= Nc) { Rcol[j] = 0.0; Crow[j] = 0.0; }
-        if (!live) st_i = 0.0;
-    } else if (w1) {
-#pragma unroll
-        for (int j = 0; j < kNcMax; j++) { Rcol[j] = 0.0; Crow[j] = 0.0; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < kNcMax; j++) { Rcol[j] = 0.0; Crow[j] = 0.0; }
-        // ---- core block and core state (wave 0): lane = (row group, column), all gathers issued before the first store ----
-        constexpr int kRounds = (kNcMax * kNcMax + 63) / 64;
-        double cbv[kRounds];
-#pragma unroll
-        for (int q = 0; q < kRounds; q++) {
-            const int e = lane + 64 * q;
-            const int j = min(e / kNcMax, kNcMax - 1), c = e - (e / kNcMax) * kNcMax;   // compile-time divisor
-            cbv[q] = Sg[(size_t)sh_cidx[j] * ld + sh_cidx[c]];   // positions beyond Nc are clamped copies, never used
-        }
-        const double scv = st[sh_cidx[lane < kNcMax ? lane : 0]];
-#pragma unroll
-        for (int q = 0; q < kRounds; q++) {
-            const int e = lane + 64 * q;
-            if (e < kNcMax * kNcMax) sh_Cb[e / kNcMax][e % kNcMax] = cbv[q];
-        }
-        if (lane < kNcMax) sh_sc[lane] = scv;
-        // factors of unused core rows are exact zeros (the slices run their loops to kNcMax)
-        for (int e = lane; e < kCallV * kNcMax; e += 64) { sh_Kc[e / kNcMax][e % kNcMax][0] = 0.0; sh_Kc[e / kNcMax][e % kNcMax][1] = 0.0; }
-        for (int e = lane; e < kCallV * (kNcMax + 1); e += 64) { sh_Gc[e / (kNcMax + 1)][0][e % (kNcMax + 1)] = 0.0; sh_Gc[e / (kNcMax + 1)][1][e % (kNcMax + 1)] = 0.0; }
-    }
-    if (tid >= 64 && tid < 67) {
-        // (with a folded prediction the pose of the call is the PREDICTED pose: theta is not wrapped, :99)
-        const double pk = src.has_twist ? pose_k + sh_pr[2 + tid - 64] : pose_k;
-        sh_pose[tid - 64] = pk;
-        if (blockIdx.x == 0 && src.fresh_pose) pv.snap[(size_t)b * 4 + tid - 64] = pk;
-    }
-    CF_TR(0, 1); CF_TR(1, 1);
-    __syncthreads();
+    auto terms_ang = [&](int v) {
+        wave_terms_ang(lane, sh_sc[3 + 2 * v], sh_sc[4 + 2 * v], sh_zs[v][0], sh_zs[v][1], theta, x, y, true, &sh_tv[v][15]);
+    };
+    // Between P1 and P2: the state-only terms of correction 0 (waves 1 and 2: they need the pose and the landmark, not the
+    // block) beside the prediction folded into what this workgroup holds (wave 0: the block; the slices: their panels).
+    if (wave == 1 && cnt > 0) terms_ang(0);
+    if (wave == 2 && cnt > 0) terms_geo(0);
     if (src.has_twist) {
-        // ---- prediction(), :101-102, on what this workgroup holds (the structured arithmetic of k_predict) ----
+        // ---- prediction(), :101-102 (the structured arithmetic of k_predict) ----
         const double a10 = sh_pr[0], a20 = sh_pr[1];
         if (w0) {
             // core block: rows / columns 1, 2 beyond the pose block, then the 3 x 3 block from its OLD values
@@ -264,15 +293,14 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
             Crow[1] = Crow[0] * a10 + Crow[1];   // columns 1, 2 of row i
             Crow[2] = Crow[0] * a20 + Crow[2];
         }
-        __syncthreads();
-        if (live && i < 3) {   // pose rows / columns: they ARE rows / columns of the (now predicted) core block
-#pragma unroll
-            for (int j = 0; j < kNcMax; j++)
-                if (j < Nc) { Rcol[j] = sh_Cb[j][i]; Crow[j] = sh_Cb[i][j]; }
-            st_i = st_i + sh_pr[2 + i];
-        }
     }
-    const double theta = sh_pose[0], x = sh_pose[1], y = sh_pose[2];
+    __syncthreads();   // P2: the block is predicted, correction 0's state-only terms are in LDS
+    if (src.has_twist && live && i < 3) {   // pose rows / columns: they ARE rows / columns of the (now predicted) core block
+#pragma unroll
+        for (int j = 0; j < kNcMax; j++)
+            if (j < Nc) { Rcol[j] = sh_Cb[j][i]; Crow[j] = sh_Cb[i][j]; }
+        st_i = st_i + sh_pr[2 + i];
+    }
     CF_TR(0, 2); CF_TR(1, 2);
 
     // ---- the core filter, pipelined over two wavefronts, and the slices ----
@@ -300,40 +328,54 @@ __global__ __launch_bounds__(128 + SLICE) void k_call_factors(PoolView pv, CallS
             sh_sc[lane] = sv;
         }
     };
-    auto terms_h = [&](int v) {
-        wave_terms_h(lane, sh_sc[3 + 2 * v], sh_sc[4 + 2 * v], sh_zs[v][0], sh_zs[v][1], theta, x, y, true, &sh_tv[v][0], &sh_tv[v][14]);
-    };
     auto terms_s = [&](int v) {
         auto s55 = [&](int k, int l) { return sh_Cb[core5(k, v)][core5(l, v)]; };
         wave_sync_lds();
         wave_terms_s(lane, &sh_tv[v][0], pv.p.r_meas, s55, &sh_tv[v][10]);
         wave_sync_lds();
     };
-    // Three roles, each with its own loop over the corrections; every wave passes the same sequence of workgroup
-    // barriers -- A(t) in front of step t, B(t) behind its first phase when a correction t + 1 follows:
-    //   wave 0   the serial chain: phase 1 of step t = the state-only half of correction t + 1 (its landmark is up to
-    //            date: the core state was advanced with the gains of t); phase 2 = S, S^-1 from the updated block, the
-    //            gains and the core state of t + 1
-    //   wave 1   phase 1: the core block's own rank-2 update for correction t
+    // Four roles, each with its own loop over the corrections; every wave passes the same sequence of workgroup
+    // barriers -- P1, P2 above, then A(t) in front of step t and B(t) behind its first phase when a correction t + 1
+    // follows.  Phase 1 of step t works on correction t + 1's state-only terms (its landmark is up to date: the core state
+    // was advanced with the gains of t) beside correction t's updates; phase 2 finishes t + 1:
+    //   wave 0   phase 1: geometry of t + 1 (ranges, the quotients of H, nu0: one sqrt and one division deep);
+    //            phase 2: S, S^-1 from the updated block, the gains and the core state of t + 1
+    //   wave 1   phase 1: angles of t + 1 (the two atan2, the wraps, nu1) -- beside wave 0, not in front of it: the
+    //            per-correction chain is max(geometry, angles) + phase 2 instead of their sum
+    //   wave 2   phase 1: the core block's own rank-2 update for correction t
     //   slices   phase 1: factors of correction t for their index, panels and state updated
-    // The loops of waves 0 and 1 are ROLLED: the chain's code (atan2, sqrt, the quotients: ~1000 instructions per
-    // correction) is fetched once and then runs from the instruction cache.  Unrolled eight times -- as the slices' loop
-    // must be, their panels live in statically indexed registers -- the kernel was 17 k instructions of straight-line code
-    // that every workgroup fetched cold, correction after correction (3.3 us per correction against ~1.2 us for the chain).
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (correction 0's phase 1 ran between P1 and P2, its geometry on wave 2.)
+    // The loops of the control waves are ROLLED: their code is fetched once and then runs from the instruction cache.
+    // (Unrolled eight times -- as the slices' loop must be, their panels live in statically indexed registers -- the
+    // kernel was 17 k instructions of straight-line code that every workgroup fetched cold: 2.05 us per correction; rolled:
+    // 1.70 us, the chain of one wavefront at ~9 cycles per dependent fp64 instruction; with the angles on their own
+    // wave: 1.5 us.)
     if (wave == 0) {
+        if (cnt > 0) { terms_s(0); core_gains(0); }
 #pragma nounroll
-        for (int t = -1; t < cnt; t++) {   // (t = -1: the prologue, correction 0 up to its gains, no barrier yet)
-            if (t >= 0) { __syncthreads(); CF_TR(0, 3 + 5 * t); }
+        for (int t = 0; t < cnt; t++) {
+            __syncthreads();
+            CF_TR(0, 3 + 5 * t);
             if (t + 1 < cnt) {
-                terms_h(t + 1);
-                if (t >= 0) { CF_TR(0, 4 + 5 * t); __syncthreads(); CF_TR(0, 5 + 5 * t); }
+                terms_geo(t + 1);
+                CF_TR(0, 4 + 5 * t);
+                __syncthreads();
+                CF_TR(0, 5 + 5 * t);
                 terms_s(t + 1);
                 core_gains(t + 1);
-                if (t >= 0) CF_TR(0, 6 + 5 * t);
+                CF_TR(0, 6 + 5 * t);
             }
         }
     } else if (wave == 1) {
+#pragma nounroll
+        for (int t = 0; t < cnt; t++) {
+            __syncthreads();
+            if (t + 1 < cnt) {
+                terms_ang(t + 1);
+                __syncthreads();
+            }
+        }
+    } else if (wave == 2) {
 #pragma nounroll
         for (int t = 0; t < cnt; t++) {
             __syncthreads();
@@ -578,10 +620,10 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
 void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, double* V, int* cnt, double* state_out,
                          hipStream_t s) {
     if ((long long)pv.B * ((pv.ld + 255) / 256) >= 128)
-        hipLaunchKernelGGL(k_call_factors<256>, dim3((pv.ld + 255) / 256, pv.B), dim3(128 + 256), 0, s, pv, src, U, V, cnt,
+        hipLaunchKernelGGL(k_call_factors<256>, dim3((pv.ld + 255) / 256, pv.B), dim3(kCtl + 256), 0, s, pv, src, U, V, cnt,
                            state_out, rank2v_round_count(src.vcount));
     else
-        hipLaunchKernelGGL(k_call_factors<64>, dim3((pv.ld + 63) / 64, pv.B), dim3(128 + 64), 0, s, pv, src, U, V, cnt,
+        hipLaunchKernelGGL(k_call_factors<64>, dim3((pv.ld + 63) / 64, pv.B), dim3(kCtl + 64), 0, s, pv, src, U, V, cnt,
                            state_out, rank2v_round_count(src.vcount));
 }
 

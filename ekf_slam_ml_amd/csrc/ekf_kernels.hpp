@@ -304,6 +304,40 @@ __device__ __forceinline__ void wave_terms_h(int lane, double tx, double ty, dou
     }
 }
 
+// wave_terms_h in two parts for two wavefronts that run side by side: the GEOMETRY part (ranges, the quotients of H,
+// nu0: one sqrt and one division deep) and the ANGLE part (the two atan2, the wraps, nu1) share no intermediate result
+// beyond delta, so the per-correction chain of a single filter is max(geometry, angle) instead of their sum.
+// Same operations as wave_terms_h, result for result.
+__device__ __forceinline__ void wave_terms_geo(int lane, double tx, double ty, double sx, double sy, double x, double y,
+                                               double* outH, double* outNu0) {
+    const double delta_x = tx - x, delta_y = ty - y;
+    const double d = delta_x * delta_x + delta_y * delta_y;
+    const bool pred = lane & 1;
+    const double px = pred ? delta_x : sx, py = pred ? delta_y : sy;
+    const double sq = sqrt(px * px + py * py);
+    const double z0 = lane_bcast(sq, 0);
+    const double sd = lane_bcast(sq, 1);
+    const int q = lane & 7;
+    const double num = (q == 0 || q == 3) ? -delta_x : (q == 1 || q == 6) ? -delta_y : (q == 2 || q == 5) ? delta_y : delta_x;
+    const double den = (q == 0 || q == 1 || q == 4 || q == 5) ? sd : d;
+    const double hq = num / den;
+    if (lane < 8) outH[q < 2 ? 1 + q : q < 4 ? 4 + q : q < 6 ? q - 1 : 2 + q] = hq;
+    if (lane == 8) outH[0] = 0.0;
+    if (lane == 9) outH[5] = -1.0;
+    if (lane == 0) *outNu0 = z0 - sd;                                  // :182
+}
+__device__ __forceinline__ void wave_terms_ang(int lane, double tx, double ty, double sx, double sy, double theta, double x,
+                                               double y, bool wrap_nu, double* outNu1) {
+    const double delta_x = tx - x, delta_y = ty - y;
+    const bool pred = lane & 1;
+    const double px = pred ? delta_x : sx, py = pred ? delta_y : sy;
+    const double at = atan2(py, px);
+    const double z1 = lane_bcast(at, 0);
+    const double atd = lane_bcast(at, 1);
+    const double zh1 = normalize_angle(atd - theta);                   // :152-155
+    if (lane == 0) *outNu1 = wrap_nu ? normalize_angle(z1 - zh1) : z1 - zh1;   // :183
+}
+
 template <class S55Fn>
 __device__ __forceinline__ void wave_terms_s(int lane, const double* H, double r_meas, S55Fn s55, double* outSi) {
     const int ha = (lane / 5) & 1, hl = lane % 5;
