@@ -734,6 +734,8 @@ def main():
     # ekf_slam.cpp:300-309) and the winner corrected at full width (:331-390): four launches per measurement slot.
     if not a.no_unknown and not a.host_log:
         Bl, J, Tu = min(B, 512), 8, 1 + W + K
+        kdl = 32                                  # delayed variant: corrections per flush ...
+        Kdl = -(-K // (kdl // J)) * (kdl // J)    # ... and its step count: whole flushes (kdl / J steps each)
         lb = capi.BatchEKF(Bl, n, device=local)
         lworld = synth.make_world(n, 12.0, 0.6, 3)
         rng = np.random.default_rng(1000 + rank)
@@ -752,7 +754,7 @@ def main():
         lb.run_known(0, Ta)
         lb.set_call_fused(False)
         lb.set_known_counts(n)
-        lcfg = synth.config3(steps=Tu)
+        lcfg = synth.config3(steps=Tu + Kdl)
         lcfg.filters, lcfg.first_filter_id, lcfg.n = Bl, rank * Bl, n
         lb.simulate_unknown_log(lcfg, lworld, jmax=J)
         lb.run_unknown(0, 1 + W)
@@ -779,13 +781,53 @@ def main():
                 "covariance_GBps": Bl * 16.0 * N * N / r2_s / 1e9,
                 "frac_of_8TBps_in_the_pass": Bl * 16.0 * N * N / r2_s / 1e9 / HBM_PEAK_GBS,
                 "frac_of_8TBps_end_to_end": lsteps / lwall * 16.0 * N * N / 1e9 / HBM_PEAK_GBS,
-                "mc_consistency": lb.mc_stats(Tu - 1),
+                "mc_consistency": dict(lb.mc_stats(Tu - 1), step=Tu - 1),
                 "note": "known_count = n for every filter (map surveyed through the known-association path first): the "
                         "discovered prefix is the whole state.  Two launches per step: a workgroup per filter scores every "
                         "reading against all n landmarks, decides and builds the gains against the stored covariance minus "
                         "the step's pending pairs (ekf_stepfused.hip); one pass of ekf::k_rank2v (K values staged in LDS) then "
                         "streams every 32-MB covariance ONCE per step (covariance_GBps = filters x 16 N^2 B per pass); "
                         "bit-identical to four launches per measurement slot"}
+        # The same leg in DELAYED mode (ekf_batch_set_update_mode): the pairs of a step stay pending across steps, every
+        # reading is scored and corrected against the stored covariance minus all pending pairs, Sigma is rewritten once per
+        # kdl / J steps.  Timed over the steps that follow the eager leg's; parity against an eager side pool of the first
+        # filters (same global ids -> same survey noise and readings) that runs the whole sequence eagerly.
+        lb.set_update_mode(kdl)
+        fence()
+        t0 = time.perf_counter()
+        sd2 = lb.run_unknown(Tu, Tu + Kdl, time_kernels=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fence()
+        dwall2, dcorr2, dsteps2 = shard.reduce_throughput(t1 - t0, float(sd2["corrections"]), float(sd2["filter_steps"]),
+                                                          device=red_dev)
+        if rank == 0:
+            nref = min(Bl, 8)
+            ref = capi.BatchEKF(nref, n, device=local)
+            ref.upload_known_log(np.zeros((Ta, nref, 2)), a_lm[:, :nref], a_z[:, :nref], a_init[:nref])
+            ref.run_known(0, Ta)
+            ref.set_known_counts(n)
+            import copy
+            rcfg = copy.copy(lcfg)
+            rcfg.filters = nref
+            ref.simulate_unknown_log(rcfg, lworld, jmax=J)
+            ref.run_unknown(0, Tu + Kdl)
+            dec_d, dec_e = lb.decisions()[:, :nref], ref.decisions()
+            sdiff = max(float(np.abs(lb.state(b) - ref.state(b)).max()) for b in range(nref))
+            c_d, c_e = lb.cov(0), ref.cov(0)
+            out["unknown_association_large_prefix"]["delayed"] = {
+                "value": dsteps2 / dwall2, "unit": "filter steps/s", "corrections_per_flush": kdl, "steps": Kdl,
+                "steps_per_flush": kdl // J, "flushes": sd2["rank2_launches"],
+                "flush_avg_ms": sd2["rank2_ms"] / max(sd2["rank2_launches"], 1),
+                "corrections_per_s": dcorr2 / dwall2, "speedup_vs_eager": (dsteps2 / dwall2) / (lsteps / lwall),
+                "parity_filters": nref, "decisions_identical_to_eager": bool(np.array_equal(dec_d, dec_e)),
+                "max_abs_state_diff_vs_eager": sdiff,
+                "max_rel_cov_diff_vs_eager": float(np.abs(c_d - c_e).max() / np.abs(c_e).max()),
+                "mc_consistency": dict(lb.mc_stats(Tu + Kdl - 1), step=Tu + Kdl - 1),
+                "note": "pools' data_association() in delayed mode: jmax = 8 pairs per step and filter stay pending across "
+                        "steps (ekf_stepfused.hip, DELAYED), one flush per 4 steps instead of one pass per step; "
+                        "tests/test_gpu_batch_unknown.py::test_delayed_data_association_for_pools"}
+            ref.close()
         lb.close()
     # The reference's own operating point at Monte-Carlo scale: configs[0] (n = 20, 1000 steps) for 8192 robots per
     # GPU, inputs simulated on the device, the whole run ONE launch with every covariance resident in LDS.

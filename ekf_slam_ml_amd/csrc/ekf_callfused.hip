@@ -481,22 +481,8 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
     if (row_begin >= N) return;   // (uniform)
     const double* __restrict__ Ub = Uall + (size_t)b * 2 * kCallV * ld;
     __shared__ double2_t sh_Kl[KL ? 128 : 1][CNT];
-    if constexpr (KL) {   // rows fastest: consecutive threads read consecutive rows of one K vector
-        const int nrows = row_end - row_begin;   // <= 128 (launcher)
-        for (int e = threadIdx.x; e < nrows * CNT; e += 256) {
-            const int v = e / nrows, rr = e - v * nrows;
-            sh_Kl[rr][v] = double2_t{Ub[(size_t)(2 * v) * ld + row_begin + rr], Ub[(size_t)(2 * v + 1) * ld + row_begin + rr]};
-        }
-        __syncthreads();
-    }
-    if (c2 >= ld2a) return;
     const double2_t* __restrict__ Vb2 = reinterpret_cast<const double2_t*>(Vall + (size_t)b * 2 * kCallV * ld);
     double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + c2;
-
-    double2_t g0[CNT], g1[CNT];
-#pragma unroll
-    for (int v = 0; v < CNT; v++) { g0[v] = Vb2[(size_t)(2 * v) * ld2n + c2]; g1[v] = Vb2[(size_t)(2 * v + 1) * ld2n + c2]; }
-
     auto load_group = [&](double2_t (&buf)[UR], int row) {
 #pragma unroll
         for (int u = 0; u < UR; u++) {
@@ -505,6 +491,40 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
             else buf[u] = *p;
         }
     };
+    const int nfull = (row_end - row_begin) / UR;  // uniform
+    const bool col_live = c2 < ld2a;
+    double2_t A[UR];
+    double2_t g0[CNT], g1[CNT];
+    if constexpr (KL) {
+        // A workgroup lives for ~20 us; its K values (global -> LDS -> barrier), its G values and its first row group are
+        // three round trips if taken one after the other -- a fifth of its life.  All three are requested at once.
+        constexpr int kPer = (128 * CNT + 255) / 256;   // K entries staged per thread (rows fastest: consecutive
+        const int nrows = row_end - row_begin;          // threads read consecutive rows of one K vector); <= 128 rows
+        double2_t kst[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int e = threadIdx.x + 256 * q;
+            const int v = min(e / nrows, CNT - 1), rr = e - (e / nrows) * nrows;
+            kst[q] = double2_t{Ub[(size_t)(2 * v) * ld + row_begin + rr], Ub[(size_t)(2 * v + 1) * ld + row_begin + rr]};
+        }
+        if (col_live) {
+            if (nfull > 0) load_group(A, row_begin);
+#pragma unroll
+            for (int v = 0; v < CNT; v++) { g0[v] = Vb2[(size_t)(2 * v) * ld2n + c2]; g1[v] = Vb2[(size_t)(2 * v + 1) * ld2n + c2]; }
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int e = threadIdx.x + 256 * q;
+            if (e < nrows * CNT) sh_Kl[e - (e / nrows) * nrows][e / nrows] = kst[q];
+        }
+        __syncthreads();
+        if (!col_live) return;
+    } else {
+        if (!col_live) return;
+#pragma unroll
+        for (int v = 0; v < CNT; v++) { g0[v] = Vb2[(size_t)(2 * v) * ld2n + c2]; g1[v] = Vb2[(size_t)(2 * v + 1) * ld2n + c2]; }
+    }
+
     auto apply = [&](double2_t& x, int row) {
 #pragma unroll
         for (int v = 0; v < CNT; v++) {
@@ -561,22 +581,35 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
             }
         }
     };
+    // corrections outermost, rows innermost: for one correction the UR rows x 2 columns of a lane are 2 UR independent
+    // short chains, so the fp64 pipe always has an instruction that does not wait for the previous one (rows outermost,
+    // one element runs its CNT dependent updates back to back: PMC showed the waves of an 8-correction pass stalled on
+    // instruction issue for half of their cycles).  Per element the corrections are still applied in order.
     auto finish_group = [&](double2_t (&buf)[UR], int row) {
         predict_group(buf, row);
 #pragma unroll
+        for (int v = 0; v < CNT; v++) {
+#pragma unroll
+            for (int u = 0; u < UR; u++) {
+                double k0, k1;
+                if constexpr (KL) { const double2_t kk = sh_Kl[row + u - row_begin][v]; k0 = kk.x; k1 = kk.y; }
+                else { k0 = Ub[(size_t)(2 * v) * ld + row + u]; k1 = Ub[(size_t)(2 * v + 1) * ld + row + u]; }   // uniform -> s_load
+                buf[u].x = buf[u].x - (k0 * g0[v].x + k1 * g1[v].x);
+                buf[u].y = buf[u].y - (k0 * g0[v].y + k1 * g1[v].y);
+            }
+        }
+#pragma unroll
         for (int u = 0; u < UR; u++) {
-            apply(buf[u], row + u);
             double2_t* p = col + (size_t)(row + u) * ld2n;
             if constexpr (NT) __builtin_nontemporal_store(buf[u], p);
             else *p = buf[u];
         }
     };
 
-    const int nfull = (row_end - row_begin) / UR;  // uniform
     int r = row_begin;
     if (nfull > 0) {
-        double2_t A[UR], Bf[UR], Cf[UR];
-        load_group(A, r);
+        double2_t Bf[UR], Cf[UR];
+        if constexpr (!KL) load_group(A, r);
         int g = 0;
         for (; g + 3 < nfull; g += 3) {  // invariant: A holds group g; no branch inside
             load_group(Bf, r + UR);
@@ -666,12 +699,13 @@ void launch_rank2v(const PoolView& pv, const double* U, const double* V, const i
     if (c >= 4 && rows == 64 && t.rows_per_block <= 0) rows = 32;
     const bool big = rows >= 32;
     const bool u16 = big && t.group_rows != 8;
+    const bool u8 = big && t.group_rows != 4;   // (passes of >= 4 corrections: 8-row groups unless the tuning asks for 4)
     switch (c) {
         case 1: u16 ? launch_rank2v_c<16, 1>(pv, U, V, cnt, nt, rows, s, pred) : big ? launch_rank2v_c<8, 1>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, 1>(pv, U, V, cnt, nt, rows, s, pred); break;
         case 2: u16 ? launch_rank2v_c<16, 2>(pv, U, V, cnt, nt, rows, s, pred) : big ? launch_rank2v_c<8, 2>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, 2>(pv, U, V, cnt, nt, rows, s, pred); break;
-        case 4: big ? launch_rank2v_c<8, 4>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, 4>(pv, U, V, cnt, nt, rows, s, pred); break;
-        case 6: big ? launch_rank2v_c<8, 6>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, 6>(pv, U, V, cnt, nt, rows, s, pred); break;
-        default: big ? launch_rank2v_c<8, kCallV>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, kCallV>(pv, U, V, cnt, nt, rows, s, pred); break;
+        case 4: u8 ? launch_rank2v_c<8, 4>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, 4>(pv, U, V, cnt, nt, rows, s, pred); break;
+        case 6: u8 ? launch_rank2v_c<8, 6>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, 6>(pv, U, V, cnt, nt, rows, s, pred); break;
+        default: u8 ? launch_rank2v_c<8, kCallV>(pv, U, V, cnt, nt, rows, s, pred) : launch_rank2v_c<4, kCallV>(pv, U, V, cnt, nt, rows, s, pred); break;
     }
 }
 

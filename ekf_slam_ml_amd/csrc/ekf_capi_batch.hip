@@ -303,10 +303,16 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     if (P.uT <= 0) return fail(EKF_ERR_STATE, "ekf_batch_run_unknown: no unknown-association log uploaded");
     if (t_begin < 0 || t_end > P.uT || t_begin > t_end) return fail(EKF_ERR_INVALID, "step range outside the uploaded log");
     EKFC(P.use());
-    EKFC(P.flush());
+    const int B = P.pv.B, n = P.pv.n, jmax = P.ujmax;
+    // Delayed mode (ekf_batch_set_update_mode(k > 0)): the step-fused form keeps the pairs of a step pending ACROSS steps in
+    // the pool's factor store -- jmax pairs per step and filter, Sigma rewritten once per floor(k / jmax) steps instead of
+    // once per step.  Everything else (the LDS-resident small-map steps, four launches per slot) works on the materialised
+    // covariance and flushes first.
+    const bool delayed = P.pend_cap > 0 && P.step_fused && jmax > 0 && jmax <= ekf::kCallV && 2 * jmax <= P.pend_cap &&
+                         P.pend_cap / 2 <= ekf::step_pending_pairs_max();
+    if (!delayed) EKFC(P.flush());
     P.alt_synced = false;
     P.dev_known_count = -1;
-    const int B = P.pv.B, n = P.pv.n, jmax = P.ujmax;
     size_t launches = 0;
     for (int t = t_begin; t < t_end; t++) {
         const int* ct = P.ucount_host.data() + (size_t)t * B;
@@ -316,7 +322,7 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     }
     hipEvent_t* ev = nullptr;
     if (time_kernels && launches) {
-        ev = P.events(2 * launches);
+        ev = P.events(2 * (launches + (size_t)(t_end - t_begin) + 2));   // (+ flushes of the delayed mode)
         if (!ev) return fail(EKF_ERR_HIP, "hipEventCreate failed");
     }
     HIPC(hipMemsetAsync(P.corr_counter, 0, sizeof(unsigned long long), P.stream));
@@ -338,6 +344,14 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     std::vector<int> kc(B, 0);
     size_t k = 0;
     int kc_max = 0;
+    auto timed_flush = [&]() -> ekf_status {
+        if (P.pend_count == 0) return EKF_OK;
+        if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
+        EKFC(P.flush());
+        if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
+        k++;
+        return EKF_OK;
+    };
     // Small discovered prefixes: while every filter's 3 + 2*(known_count + readings of the step) fits the
     // LDS-resident path, ONE launch per step does all scoring, gating, initialisation and corrections of the step
     // for the whole pool (k_pool_associate) instead of four launches per measurement slot.
@@ -375,6 +389,7 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
             ekf::launch_predict(pvp, P.ulog_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream);
         }
         if (want_small && smax > 0 && Nstep <= ekf::small_max_dim()) {
+            if (delayed) EKFC(timed_flush());   // (the LDS-resident step works on the materialised covariance)
             pva.N = Nstep;
             if ((Nstep - 3) / 2 > kc_max) kc_max = (Nstep - 3) / 2;
             if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
@@ -382,6 +397,19 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
                                        3 + 2 * P.touched_hwm, P.ulog_assoc + (size_t)t * B * jmax, P.corr_counter, P.stream);
             if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
             k++;
+            smax = 0;  // the step is done
+        }
+        if (smax > 0 && delayed) {
+            // the step's pairs join the pending store (ekf_stepfused.hip, DELAYED): no pass over Sigma in this step
+            EKFC(P.ensure_callfused());
+            if (Nstep > 3 + 2 * kc_max) kc_max = (Nstep - 3) / 2;
+            if (P.pend_count + 2 * jmax > P.pend_cap) EKFC(timed_flush());
+            ekf::launch_pool_step_unknown_delayed(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
+                                                  P.active_prefix ? 3 + 2 * P.touched_hwm : P.pv.N,
+                                                  P.ulog_assoc + (size_t)t * B * jmax, P.pending(), P.corr_counter, P.cf_cnt,
+                                                  P.stream);
+            P.pend_count += 2 * jmax;
+            P.form_counts[5]++;
             smax = 0;  // the step is done
         }
         if (smax > 0 && P.step_fused && jmax <= ekf::kCallV && P.pend_cap == 0) {
@@ -422,6 +450,7 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
             k++;
             smax = 0;  // the step is done
         }
+        if (smax > 0) EKFC(P.flush());   // (four launches per slot: on the materialised covariance)
         for (int j = 0; j < smax; j++) {  // ekf_slam.cpp:291: sequential, state-carrying
             int m_before = 0, m = 0;      // bounds of known_count before / after this slot's decision
             for (int b = 0; b < B; b++) {
@@ -450,6 +479,7 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
         }
         for (int b = 0; b < B; b++) { kc[b] += ct[b]; if (kc[b] > n) kc[b] = n; }
     }
+    if (delayed) EKFC(timed_flush());   // every run leaves Sigma materialised
     HIPC(hipEventRecord(P.ev_end, P.stream));
     EKFC(checked_launch());
     unsigned long long corr = 0;

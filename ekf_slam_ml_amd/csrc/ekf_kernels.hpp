@@ -509,6 +509,13 @@ int rank2v_round_count(int vcount);   // corrections per pass, rounded up to an 
 void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                               int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s,
                               int* cnt_out = nullptr, int zero_upto = 0);
+// Delayed mode: the step's pairs (exactly jmax per filter, zero pairs beyond a filter's own readings) are appended to the
+// pool's pending store behind the pend.count / 2 pairs of earlier steps, which the step's readings see subtracted; nothing
+// is applied to Sigma (the caller flushes every few steps).  cnt_scratch: [B] ints.
+void launch_pool_step_unknown_delayed(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
+                                      int* assoc_out, const Pending& pend, unsigned long long* corr_counter, int* cnt_scratch,
+                                      hipStream_t s);
+int step_pending_pairs_max();   // pairs a filter can carry between flushes in that mode
 
 int max_pending();  // capacity limit of the delayed-update factor store (rows of U / V per filter)
 void launch_gather_poses(const PoolView& pv, double* out, hipStream_t s);

@@ -24,28 +24,46 @@
 namespace ekf {
 
 constexpr int kStepThreads = 512;
+constexpr int kStepPendingPairs = 64;   // delayed mode: pairs a filter can carry between flushes (= max_pending() / 2)
 
+// DELAYED (ekf_batch_set_update_mode(k > 0), SURVEY.md section 8(f) f2 applied to data_association): the pairs of a step are
+// not applied at its end but stay pending ACROSS steps in the pool's factor store (prediction() maps them, k_predict);
+// this step's readings see the covariance as "stored minus ALL pending pairs": p0 pairs from earlier steps + its own.
+// The store is flushed every few steps (k_flush: one pass over Sigma per flush instead of per step).  Every filter appends
+// exactly `zero_upto` pairs per step (zero pairs beyond its own readings), so the pending count stays uniform over the pool.
+template <bool DELAYED>
 __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv, const double* __restrict__ meas_all,
                                                                     const int* __restrict__ count, int jmax, int min_active,
                                                                     int* __restrict__ assoc_out, double* __restrict__ Uall,
                                                                     double* __restrict__ Vall,
                                                                     unsigned long long* __restrict__ corr_counter,
-                                                                    int* __restrict__ cnt_out, int zero_upto) {
+                                                                    int* __restrict__ cnt_out, int zero_upto, int p0,
+                                                                    int pair_rows) {
+    constexpr int kPairs = DELAYED ? kStepPendingPairs : kCallV;
     // cnt_out == nullptr: the final pass runs here (one workgroup streams its filter's covariance).  Otherwise the step
     // ends with the pairs in Uall / Vall (rows beyond the filter's pair count zero-filled up to `zero_upto` pairs) and
     // cnt_out[b] pairs -- the caller streams all covariances with k_rank2v, which spreads every filter over the chip.
     const int b = blockIdx.x, tid = threadIdx.x;
     const int J = count ? count[b] : jmax;
+    const int n = pv.n, ld = pv.ld;
     if (J <= 0) {  // uniform
         if (cnt_out && tid == 0) cnt_out[b] = 0;
+        if constexpr (DELAYED) {   // the step's share of the pending store: zero pairs
+            double* Uz = Uall + (size_t)b * pair_rows * ld;
+            double* Vz = Vall + (size_t)b * pair_rows * ld;
+            for (int r = tid; r < ld; r += kStepThreads)
+                for (int v = p0; v < p0 + zero_upto; v++) {
+                    Uz[(size_t)(2 * v) * ld + r] = 0.0; Uz[(size_t)(2 * v + 1) * ld + r] = 0.0;
+                    Vz[(size_t)(2 * v) * ld + r] = 0.0; Vz[(size_t)(2 * v + 1) * ld + r] = 0.0;
+                }
+        }
         return;
     }
-    const int n = pv.n, ld = pv.ld;
     // (no __restrict__: the pairs and the state are written and re-read by this workgroup, ordered by its barriers)
     double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
     double* st = pv.state + (size_t)b * ld;
-    double* Ub = Uall + (size_t)b * 2 * kCallV * ld;
-    double* Vb = Vall + (size_t)b * 2 * kCallV * ld;
+    double* Ub = Uall + (size_t)b * pair_rows * ld;
+    double* Vb = Vall + (size_t)b * pair_rows * ld;
     const double* meas = meas_all + (size_t)b * jmax * 2;
     int* out = assoc_out + (size_t)b * jmax;
 
@@ -56,7 +74,7 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
     __shared__ double2_t sh_K[32][kCallV];   // K_v of a row block of the final pass
     // pending pairs at the five indices c5 of the landmark in hand: [v][0..2] = pose rows / columns (kept up to date as
     // pairs are appended), [v][3..4] = the winner's two rows / columns (fetched after the decision)
-    __shared__ double sh_K5[kCallV][5][2], sh_G5[kCallV][5][2];
+    __shared__ double sh_K5[kPairs][5][2], sh_G5[kPairs][5][2];
 
     const int kc0 = pv.assoc[b].known_count;
     // the filter's active dimension for this step: rows / columns beyond it still hold constructor values, where K and G
@@ -65,9 +83,16 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
     if (min_active > Nb) Nb = min_active;
     if (Nb > pv.N) Nb = pv.N;
     if (tid == 0) { sh_M = kc0; sh_applied = 0; }
+    if constexpr (DELAYED) {   // pose part of the pairs pending from earlier steps
+        for (int e = tid; e < 12 * p0; e += kStepThreads) {
+            const int v = e / 12, q = (e % 12) >> 2, h = (e >> 1) & 1, uvsel = e & 1;
+            if (uvsel == 0) sh_K5[v][q][h] = Ub[(size_t)(2 * v + h) * ld + q];
+            else sh_G5[v][q][h] = Vb[(size_t)(2 * v + h) * ld + q];
+        }
+    }
     __syncthreads();
 
-    int pc = 0;  // pending pairs of this step (uniform)
+    int pc = p0;  // pending pairs the next reading sees: earlier steps' (delayed mode) + this step's (uniform)
     for (int j = 0; j < J; j++) {  // :291 sequential, state-carrying
         const double mx = meas[2 * j], my = meas[2 * j + 1];
         const int M = sh_M;
@@ -85,20 +110,39 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
             for (int k = 0; k < 5; k++)
 #pragma unroll
                 for (int l = 0; l < 5; l++) S55[k][l] = Sg[(size_t)idx5(k, i) * ld + idx5(l, i)];
-            // the entries as they stand NOW: minus the pending pairs of this step, in order (k_rank2's expression)
-            for (int v = 0; v < pc; v++) {
+            // the entries as they stand NOW: minus the pending pairs, in order (k_rank2's expression).  The pairs' values at
+            // the landmark's two indices come from memory: two pairs are requested together (in delayed mode up to 64
+            // pairs are pending, and one round trip per pair was most of the step)
+            auto fold_pair = [&](int v, const double (&ku)[2][2], const double (&gu)[2][2]) {
                 double kr[5][2], gc[5][2];
 #pragma unroll
                 for (int k = 0; k < 3; k++) { kr[k][0] = sh_K5[v][k][0]; kr[k][1] = sh_K5[v][k][1]; gc[k][0] = sh_G5[v][k][0]; gc[k][1] = sh_G5[v][k][1]; }
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    kr[3 + q][0] = Ub[(size_t)(2 * v) * ld + ia + q]; kr[3 + q][1] = Ub[(size_t)(2 * v + 1) * ld + ia + q];
-                    gc[3 + q][0] = Vb[(size_t)(2 * v) * ld + ia + q]; gc[3 + q][1] = Vb[(size_t)(2 * v + 1) * ld + ia + q];
-                }
+                for (int q = 0; q < 2; q++) { kr[3 + q][0] = ku[q][0]; kr[3 + q][1] = ku[q][1]; gc[3 + q][0] = gu[q][0]; gc[3 + q][1] = gu[q][1]; }
 #pragma unroll
                 for (int k = 0; k < 5; k++)
 #pragma unroll
                     for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
+            };
+            auto load_pair = [&](int v, double (&ku)[2][2], double (&gu)[2][2]) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    ku[q][0] = Ub[(size_t)(2 * v) * ld + ia + q]; ku[q][1] = Ub[(size_t)(2 * v + 1) * ld + ia + q];
+                    gu[q][0] = Vb[(size_t)(2 * v) * ld + ia + q]; gu[q][1] = Vb[(size_t)(2 * v + 1) * ld + ia + q];
+                }
+            };
+            int v = 0;
+            for (; v + 2 <= pc; v += 2) {
+                double ku[2][2][2], gu[2][2][2];
+#pragma unroll
+                for (int w = 0; w < 2; w++) load_pair(v + w, ku[w], gu[w]);
+#pragma unroll
+                for (int w = 0; w < 2; w++) fold_pair(v + w, ku[w], gu[w]);
+            }
+            for (; v < pc; v++) {
+                double ku[2][2], gu[2][2];
+                load_pair(v, ku, gu);
+                fold_pair(v, ku, gu);
             }
             innovation_cov(S55, m.H, pv.p.r_meas, S);   // sums in the order of k_maha's shuffle folds
             inv2(S, Si);
@@ -194,14 +238,30 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
                     p[k] = Sg[(size_t)r * ld + c];   // column gather (Sigma * H^T reads columns)
                     g[k] = Sg[(size_t)c * ld + r];   // row gather    (H * Sigma reads rows)
                 }
-                for (int v = 0; v < pc; v++) {       // ... as they stand now: minus the pending pairs, in order
-                    const double kr0 = Ub[(size_t)(2 * v) * ld + r], kr1 = Ub[(size_t)(2 * v + 1) * ld + r];
-                    const double gr0 = Vb[(size_t)(2 * v) * ld + r], gr1 = Vb[(size_t)(2 * v + 1) * ld + r];
+                // ... as they stand now: minus the pending pairs, in order (four pairs' values requested together)
+                auto fold_rc = [&](int v, const double (&f)[4]) {
 #pragma unroll
                     for (int k = 0; k < 5; k++) {
-                        p[k] = p[k] - (kr0 * sh_G5[v][k][0] + kr1 * sh_G5[v][k][1]);
-                        g[k] = g[k] - (sh_K5[v][k][0] * gr0 + sh_K5[v][k][1] * gr1);
+                        p[k] = p[k] - (f[0] * sh_G5[v][k][0] + f[1] * sh_G5[v][k][1]);
+                        g[k] = g[k] - (sh_K5[v][k][0] * f[2] + sh_K5[v][k][1] * f[3]);
                     }
+                };
+                auto load_rc = [&](int v, double (&f)[4]) {
+                    f[0] = Ub[(size_t)(2 * v) * ld + r]; f[1] = Ub[(size_t)(2 * v + 1) * ld + r];
+                    f[2] = Vb[(size_t)(2 * v) * ld + r]; f[3] = Vb[(size_t)(2 * v + 1) * ld + r];
+                };
+                int v = 0;
+                for (; v + 4 <= pc; v += 4) {
+                    double f[4][4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) load_rc(v + w, f[w]);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) fold_rc(v + w, f[w]);
+                }
+                for (; v < pc; v++) {
+                    double f[4];
+                    load_rc(v, f);
+                    fold_rc(v, f);
                 }
                 double sht0 = 0.0, sht1 = 0.0;
 #pragma unroll
@@ -231,14 +291,14 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
 
     if (cnt_out) {   // the pass is the caller's: unused pair rows become exact no-ops
         for (int r = tid; r < ld; r += kStepThreads)
-            for (int v = pc; v < zero_upto; v++) {
+            for (int v = pc; v < p0 + zero_upto; v++) {
                 Ub[(size_t)(2 * v) * ld + r] = 0.0; Ub[(size_t)(2 * v + 1) * ld + r] = 0.0;
                 Vb[(size_t)(2 * v) * ld + r] = 0.0; Vb[(size_t)(2 * v + 1) * ld + r] = 0.0;
             }
-        if (tid == 0) cnt_out[b] = pc;
+        if (tid == 0) cnt_out[b] = pc - p0;
     }
     // ---- ONE pass over the prefix: every element takes the step's corrections in order (k_rank2's expression) ----
-    if (pc > 0 && !cnt_out) {
+    if (!DELAYED && pc > 0 && !cnt_out) {
         const int ld2n = ld >> 1, ld2a = (Nb + 1) >> 1;
         double2_t* S2 = reinterpret_cast<double2_t*>(Sg);
         const double2_t* V2 = reinterpret_cast<const double2_t*>(Vb);
@@ -301,8 +361,17 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
 void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                               int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s,
                               int* cnt_out, int zero_upto) {
-    hipLaunchKernelGGL(k_pool_step_unknown, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
-                       assoc_out, U, V, corr_counter, cnt_out, zero_upto);
+    hipLaunchKernelGGL(k_pool_step_unknown<false>, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
+                       assoc_out, U, V, corr_counter, cnt_out, zero_upto, 0, 2 * kCallV);
 }
+
+void launch_pool_step_unknown_delayed(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
+                                      int* assoc_out, const Pending& pend, unsigned long long* corr_counter, int* cnt_scratch,
+                                      hipStream_t s) {
+    hipLaunchKernelGGL(k_pool_step_unknown<true>, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
+                       assoc_out, pend.U, pend.V, corr_counter, cnt_scratch, jmax, pend.count / 2, pend.cap);
+}
+
+int step_pending_pairs_max() { return kStepPendingPairs; }
 
 }  // namespace ekf

@@ -228,7 +228,10 @@ ekf_status ekf_batch_upload_unknown_log(ekf_batch_handle hb, const ekf_unknown_l
  * gate decision / landmark initialisation (:293-330) and the correction (:331-390) of every filter
  * that has a measurement in the slot.  Each filter's known_count (the leading run of its
  * known_list, :281-288) lives on the device and carries over between runs until ekf_batch_reset.
- * Always eager (pending delayed corrections are flushed first).  stats->corrections counts the
+ * In delayed mode (ekf_batch_set_update_mode(k > 0)) with at most 8 reading slots per step, the pairs of a step stay
+ * pending across steps -- every reading is scored and corrected against the stored covariance minus ALL pending pairs,
+ * Sigma is rewritten once per floor(k / jmax) steps -- with the mode's tolerance (1e-9; decisions identical in every
+ * test); otherwise pending delayed corrections are flushed first and the run is eager.  stats->corrections counts the
  * corrections actually applied (decided on the device). */
 ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, int time_kernels,
                                  ekf_run_stats* stats);

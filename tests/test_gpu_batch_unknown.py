@@ -403,3 +403,58 @@ def test_a_non_finite_reading_stays_inside_its_filter(hip, B, n, mode):
         assert np.array_equal(res[0][0][:, b], res[1][0][:, b]) and np.array_equal(res[0][1][b], res[1][1][b]), f"filter {b}"
         if b < 8:
             assert np.array_equal(res[0][2][b], res[1][2][b]), f"filter {b} covariance"
+
+
+@pytest.mark.parametrize("k,surveyed_share", [(32, 1.0), (64, 0.6), (8, 1.0), (24, 1.0)])
+def test_delayed_data_association_for_pools(hip, oracle, k, surveyed_share):
+    """Delayed mode for pools' data_association() (ekf_slam.cpp:278-402): the pairs of a step stay pending ACROSS steps
+    (jmax = 8 pairs per step and filter; k = 32 corrections per flush -> Sigma rewritten every 4 steps, k = 64 every 8,
+    k = 8 every step, k = 24 every 3) while every reading is scored and corrected against the stored covariance minus ALL
+    pending pairs.  Decisions and known counts identical to the eager run, states and covariances within 1e-9 of it and
+    of the dense checker; ragged reading counts, filters that sit a step out, filters without a map yet (their first
+    steps run on the LDS-resident path, which flushes)."""
+    n, B, T = 150, 12, 11
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=4242, half_extent=5.0, min_spacing=0.3, max_visible_dis=1.4, vmax=8,
+                          v_cmd=1.0, w_cmd=0.6)
+    log = synth.make_unknown_log(cfg)
+    cnt = log.count.copy()
+    cnt[3, ::4] = 0                      # some filters sit a step out
+    rng = np.random.default_rng(5)
+    init = (log.world[None] + rng.normal(0.0, 0.005, size=(B, n, 2))).reshape(B, 2 * n)
+    lm0 = np.full((2, B, 1), -1, dtype=np.int32)
+    known0 = np.where(np.arange(B) < surveyed_share * B, n, 0).astype(np.int32)
+    snap = []
+    for mode in (0, k):
+        bt = hip.BatchEKF(B, n)
+        bt.upload_known_log(np.zeros((2, B, 2)), lm0, np.zeros((2, B, 1, 2)), init)
+        bt.run_known()
+        bt.set_known_counts(known0)
+        bt.set_update_mode(mode)
+        bt.upload_unknown_log(log.twist, cnt, log.meas_xy)
+        st1 = bt.run_unknown(0, 5, time_kernels=True)
+        st2 = bt.run_unknown(5, T, time_kernels=True)   # (a run boundary flushes)
+        snap.append((bt.decisions().copy(), bt.known_counts().copy(), [bt.state(b) for b in range(B)],
+                     [bt.cov(b) for b in (0, 5, B - 1)], st1, st2))
+        bt.close()
+    assert np.array_equal(snap[0][0], snap[1][0]) and np.array_equal(snap[0][1], snap[1][1])
+    for b in range(B):
+        assert np.abs(snap[0][2][b] - snap[1][2][b]).max() < 1e-9
+    for i, b in enumerate((0, 5, B - 1)):
+        assert_parity(snap[1][2][b], snap[1][3][i], snap[0][2][b], snap[0][3][i], FP64_TOL, f"delayed vs eager, filter {b}")
+    if surveyed_share == 1.0:
+        # passes over Sigma: one per step eagerly; one per floor(k / 8) steps (+ the run's closing flush) when delayed
+        assert snap[0][4]["rank2_launches"] == 5 and snap[0][5]["rank2_launches"] == 6
+        per = max(1, k // 8)
+        assert snap[1][4]["rank2_launches"] == -(-5 // per) and snap[1][5]["rank2_launches"] == -(-6 // per)
+    assert snap[0][4]["corrections"] + snap[0][5]["corrections"] == snap[1][4]["corrections"] + snap[1][5]["corrections"] > 300
+    # against the dense checker (one surveyed filter: the checker replays the survey through its known-association path)
+    b = 0
+    o, known = oracle.OracleEKF(n, oracle.DENSE), np.zeros(n, dtype=np.uint8)
+    o.prediction(0.0, 0.0); o.measurement_compact(init[b], lm0[0, b], np.zeros((1, 2)))
+    o.prediction(0.0, 0.0); o.measurement_compact(init[b], lm0[1, b], np.zeros((1, 2)))
+    known[:] = 1
+    class _L: pass
+    lg = _L(); lg.count, lg.twist, lg.meas_xy = cnt, log.twist, log.meas_xy
+    o, known, d = _oracle_replay(oracle, lg, b, n, 0, T, o, known)
+    assert np.array_equal(snap[1][0][:, b], d), "decisions differ from the checker"
+    assert_parity(snap[1][2][b], snap[1][3][0], o.state, o.cov, FP64_TOL, "delayed pool association vs dense checker")
