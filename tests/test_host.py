@@ -103,11 +103,13 @@ def test_unknown_log_shape():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r01/bench_n1.json is the line bench.py printed on the GPU box: every field of the driver's contract
-    must be there, with the roofline and cpu_baseline objects, and the numbers must be mutually consistent."""
+    """profiles/rNN/bench_n1.json (the latest round's) is the line bench.py printed on the GPU box: every field of the
+    driver's contract must be there, with the roofline and cpu_baseline objects, and the numbers must be mutually
+    consistent."""
+    import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "profiles", "r01", "bench_n1.json")
+    path = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]", "bench_n1.json")))[-1]
     line = [l for l in open(path) if l.startswith("{")][0]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
