@@ -303,36 +303,69 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
     }
     CF_TR(0, 2); CF_TR(1, 2);
 
-    // ---- the core filter, pipelined over two wavefronts, and the slices ----
-    // gains(v): K_v and G_v on the core + the core STATE update (wave 0; needs terms(v) and the block after correction v-1)
-    auto core_gains = [&](int v) {
-        if (lane < Nc) {   // lane = core row / core column
-            double sht0 = 0.0, sht1 = 0.0, g0 = 0.0, g1 = 0.0;
+    // ---- the core filter, pipelined over three wavefronts, and the slices ----
+    // phase 2 of a correction on wave 0: S, S^-1 (lane-parallel, the arithmetic of wave_terms_s) from the block after
+    // correction v - 1, then K_v on the core and the core STATE update.  Every LDS operand is requested up front; S^-1
+    // goes to LDS for the slices and stays in registers for the gains (no write -> read round trip).
+    auto core_finish = [&](int v) {
+        wave_sync_lds();
+        const int ha = (lane / 5) & 1, hl = lane % 5;
+        const int lc = lane < kNcMax ? lane : 0;
+        double s5[5], H0[5], H1[5], p[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            s5[k] = sh_Cb[core5(k, v)][core5(hl, v)];
+            H0[k] = sh_tv[v][k]; H1[k] = sh_tv[v][5 + k];
+            p[k] = sh_Cb[lc][core5(k, v)];
+        }
+        const double nu0 = sh_tv[v][14], nu1 = sh_tv[v][15], scv = sh_sc[lc];
+        double hs = 0.0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) hs += (ha ? H1[k] : H0[k]) * s5[k];
+        const int sa = (lane >> 1) & 1, sb = lane & 1;
+        double sv = 0.0;
+#pragma unroll
+        for (int l = 0; l < 5; l++) {
+            const double h0l = lane_bcast(hs, l), h1l = lane_bcast(hs, 5 + l);
+            sv += (sa ? h1l : h0l) * (sb ? H1[l] : H0[l]);
+        }
+        if (sa == sb) sv += pv.p.r_meas;
+        const double S00 = lane_bcast(sv, 0), S01 = lane_bcast(sv, 1), S10 = lane_bcast(sv, 2), S11 = lane_bcast(sv, 3);
+        const double det = S00 * S11 - S01 * S10;
+        const int sq4 = lane & 3;
+        const double si = (sq4 == 0 ? S11 : sq4 == 1 ? -S01 : sq4 == 2 ? -S10 : S00) / det;
+        if (lane < 4) sh_tv[v][10 + lane] = si;
+        const double Si0 = lane_bcast(si, 0), Si1 = lane_bcast(si, 1), Si2 = lane_bcast(si, 2), Si3 = lane_bcast(si, 3);
+        if (lane < Nc) {   // lane = core row
+            double sht0 = 0.0, sht1 = 0.0;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                const double p = sh_Cb[lane][core5(k, v)];
+                sht0 += p[k] * H0[k];
+                sht1 += p[k] * H1[k];
+            }
+            const double k0 = sht0 * Si0 + sht1 * Si2;   // :178
+            const double k1 = sht0 * Si1 + sht1 * Si3;
+            sh_Kc[v][lane][0] = k0;
+            sh_Kc[v][lane][1] = k1;
+            double st_new = scv + (k0 * nu0 + k1 * nu1);   // core state (:186-187)
+            if (lane == 0) st_new = normalize_angle(st_new);
+            sh_sc[lane] = st_new;
+        }
+    };
+    // G_v = H_v Sigma[c5(v), :] on the core columns: needs H and the updated block, not S^-1 -- wave 2, beside wave 0
+    auto core_G = [&](int v) {
+        wave_sync_lds();
+        if (lane < Nc) {   // lane = core column
+            double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
                 const double g = sh_Cb[core5(k, v)][lane];
-                sht0 += p * sh_tv[v][k];
-                sht1 += p * sh_tv[v][5 + k];
                 g0 += sh_tv[v][k] * g;
                 g1 += sh_tv[v][5 + k] * g;
             }
-            const double k0 = sht0 * sh_tv[v][10] + sht1 * sh_tv[v][12];   // :178
-            const double k1 = sht0 * sh_tv[v][11] + sht1 * sh_tv[v][13];
-            sh_Kc[v][lane][0] = k0;
-            sh_Kc[v][lane][1] = k1;
             sh_Gc[v][0][lane] = g0;
             sh_Gc[v][1][lane] = g1;
-            double sv = sh_sc[lane] + (k0 * sh_tv[v][14] + k1 * sh_tv[v][15]);   // core state (:186-187)
-            if (lane == 0) sv = normalize_angle(sv);
-            sh_sc[lane] = sv;
         }
-    };
-    auto terms_s = [&](int v) {
-        auto s55 = [&](int k, int l) { return sh_Cb[core5(k, v)][core5(l, v)]; };
-        wave_sync_lds();
-        wave_terms_s(lane, &sh_tv[v][0], pv.p.r_meas, s55, &sh_tv[v][10]);
-        wave_sync_lds();
     };
     // Four roles, each with its own loop over the corrections; every wave passes the same sequence of workgroup
     // barriers -- P1, P2 above, then A(t) in front of step t and B(t) behind its first phase when a correction t + 1
@@ -342,7 +375,7 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
     //            phase 2: S, S^-1 from the updated block, the gains and the core state of t + 1
     //   wave 1   phase 1: angles of t + 1 (the two atan2, the wraps, nu1) -- beside wave 0, not in front of it: the
     //            per-correction chain is max(geometry, angles) + phase 2 instead of their sum
-    //   wave 2   phase 1: the core block's own rank-2 update for correction t
+    //   wave 2   phase 1: the core block's own rank-2 update for correction t; phase 2: G of t + 1 on the core columns
     //   slices   phase 1: factors of correction t for their index, panels and state updated
     // (correction 0's phase 1 ran between P1 and P2, its geometry on wave 2.)
     // The loops of the control waves are ROLLED: their code is fetched once and then runs from the instruction cache.
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
     // 1.70 us, the chain of one wavefront at ~9 cycles per dependent fp64 instruction; with the angles on their own
     // wave: 1.5 us.)
     if (wave == 0) {
-        if (cnt > 0) { terms_s(0); core_gains(0); }
+        if (cnt > 0) core_finish(0);
 #pragma nounroll
         for (int t = 0; t < cnt; t++) {
             __syncthreads();
@@ -361,8 +394,7 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
                 CF_TR(0, 4 + 5 * t);
                 __syncthreads();
                 CF_TR(0, 5 + 5 * t);
-                terms_s(t + 1);
-                core_gains(t + 1);
+                core_finish(t + 1);
                 CF_TR(0, 6 + 5 * t);
             }
         }
@@ -376,6 +408,7 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
             }
         }
     } else if (wave == 2) {
+        if (cnt > 0) core_G(0);
 #pragma nounroll
         for (int t = 0; t < cnt; t++) {
             __syncthreads();
@@ -387,7 +420,7 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
                 if (j < Nc && c < Nc)
                     sh_Cb[j][c] = sh_Cb[j][c] - (sh_Kc[t][j][0] * sh_Gc[t][0][c] + sh_Kc[t][j][1] * sh_Gc[t][1][c]);
             }
-            if (t + 1 < cnt) __syncthreads();
+            if (t + 1 < cnt) { __syncthreads(); core_G(t + 1); }
         }
     } else {
 #pragma unroll

@@ -9,10 +9,14 @@ n, steps = 1000, 200
 cfg = synth.config3(steps=steps)
 log = synth.make_unknown_log(cfg)
 meas = [log.meas_xy[t, 0, :log.count[t, 0]] for t in range(steps)]
-for cf in (True, False):
+variants = [(True, 0, -1, 0), (False, 0, -1, 0)]
+if len(sys.argv) > 1:   # tuning sweep of the once-per-call pass: rows,nt,group ...
+    variants = [(True,) + tuple(int(x) for x in v.split(",")) for v in sys.argv[1:]]
+for cf, rows, nt, group in variants:
     rng = np.random.default_rng(33)
     f = capi.EKF_SLAM(n)
     f.set_call_fused(cf)
+    f.set_tuning(rows, nt, group)
     rel = synth._robot_frame(log.world, np.zeros((1, 3)))[0]
     f.measurement((rel + rng.normal(0, 0.005, rel.shape)).reshape(-1), np.zeros(n, dtype=np.uint8))
     f.measurement((rel + rng.normal(0, 0.005, rel.shape)).reshape(-1), np.ones(n, dtype=np.uint8))
@@ -24,5 +28,5 @@ for cf in (True, False):
         f.prediction(log.twist[t, 0]); nm += len(f.data_association(meas[t], kn))
     f.sync()
     dt = time.perf_counter() - t0
-    print(f"call_fused={cf}: {nm / dt:8.0f} measurements/s, {dt / nm * 1e6:6.1f} us per measurement, {dt / steps * 1e6:7.1f} us per call", flush=True)
+    print(f"call_fused={cf} rows={rows} nt={nt} group={group}: {nm / dt:8.0f} measurements/s, {dt / nm * 1e6:6.1f} us per measurement, {dt / steps * 1e6:7.1f} us per call", flush=True)
     f.close()
