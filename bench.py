@@ -571,6 +571,24 @@ def main():
                 delayed["max_abs_state_diff_vs_cpu_port"] = float(np.abs(dstate - cst).max())
                 delayed["max_rel_cov_diff_vs_cpu_port"] = float(np.abs(dcov - ccv[0]).max() / np.abs(ccv[0]).max())
             ref.close()
+        # the same leg with the opt-in symmetric gather (the gain step reads Sigma(c, r) for Sigma(r, c): coalesced rows
+        # instead of 16-KB-strided column entries; still within the mode's 1e-9, see ekf_set_update_mode)
+        bt.reset()
+        bt.set_update_mode(a.delayed_k, symmetric_gather=True)
+        bt.run_known(0, 1 + W)
+        fence()
+        t0 = time.perf_counter()
+        sg = bt.run_known(1 + W, 1 + W + Kd, time_kernels=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fence()
+        gwall, gcorr, _ = shard.reduce_throughput(t1 - t0, float(sg["corrections"]), float(sg["filter_steps"]), device=red_dev)
+        if rank == 0:
+            gstate = np.stack([bt.state(b) for b in range(nref)])
+            delayed["symmetric_gather"] = {"value": gcorr / gwall, "unit": "update steps/s",
+                                           "max_abs_state_diff_vs_eager": float(np.abs(gstate - rstate).max()),
+                                           "note": "opt-in: not the reference's operand (it reads the column); reported beside "
+                                                   "the default, never as `value` of this leg"}
         bt.set_update_mode(0)
 
     # Separately reported leg: the SAME steps with every measurement() call fused (ekf_callfused.hip) -- the gains and

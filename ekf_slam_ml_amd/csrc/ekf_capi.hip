@@ -204,7 +204,18 @@ static int assoc_call_fused_min_dim() {
 static ekf_status associate_finish(Pool& P, int known_count, int J, uint8_t* known, int* assoc_out) {
     const int n = P.pv.n;
     ekf::AssocRec rec;
-    EKFC(P.download2(&rec, P.pv.assoc, sizeof(rec), assoc_out, P.assoc_out_dev, assoc_out ? sizeof(int) * J : 0));
+    if (P.assoc_block) {   // records and decisions in one block: one copy, one synchronisation
+        const size_t bytes = Pool::kAssocDecOff + sizeof(int) * (size_t)J;
+        EKFC(P.stage_out.reserve(bytes));
+        HIPC(hipMemcpyAsync(P.stage_out.host, P.assoc_block, bytes, hipMemcpyDeviceToHost, P.stream));
+        HIPC(hipStreamSynchronize(P.stream));
+        const char* hb = static_cast<const char*>(P.stage_out.host);
+        const size_t off = reinterpret_cast<const char*>(P.pv.assoc) == P.assoc_block ? 0 : Pool::kAssocRecSlot;
+        std::memcpy(&rec, hb + off, sizeof(rec));
+        if (assoc_out) std::memcpy(assoc_out, hb + Pool::kAssocDecOff, sizeof(int) * (size_t)J);
+    } else {
+        EKFC(P.download2(&rec, P.pv.assoc, sizeof(rec), assoc_out, P.assoc_out_dev, assoc_out ? sizeof(int) * J : 0));
+    }
     for (int i = known_count; i < rec.known_count && i < n; i++) known[i] = 1;  // :323
     P.dev_known_count = rec.known_count;
     if (rec.known_count > P.touched_hwm) P.touched_hwm = rec.known_count < n ? rec.known_count : n;

@@ -95,19 +95,25 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
         px = st[1]; py = st[2];
     }
 
+    // sin and cos of theta and of theta + dtheta: even lanes take the first angle, odd lanes the second (two calls deep
+    // instead of four; same functions on the same arguments, bit for bit), broadcast through the scalar file
+    const int lane = threadIdx.x & 63;
+    const double arg = (lane & 1) ? theta + dtheta : theta;
+    const double sv = sin(arg), cv = cos(arg);
+    const double sin_t = lane_bcast(sv, 0), sin_td = lane_bcast(sv, 1), cos_t = lane_bcast(cv, 0), cos_td = lane_bcast(cv, 1);
     double u0, u1, u2, a10, a20;
     if (fabs(dtheta) < pv.p.straight_eps) {  // :79-86
         u0 = 0;
-        u1 = dx * cos(theta);
-        u2 = dx * sin(theta);
-        a10 = -dx * sin(theta);
-        a20 = dx * cos(theta);
+        u1 = dx * cos_t;
+        u2 = dx * sin_t;
+        a10 = -dx * sin_t;
+        a20 = dx * cos_t;
     } else {  // :88-94
         u0 = dtheta;
-        u1 = -(dx / dtheta) * sin(theta) + (dx / dtheta) * sin(theta + dtheta);
-        u2 = (dx / dtheta) * cos(theta) - (dx / dtheta) * cos(theta + dtheta);
-        a10 = -(dx / dtheta) * cos(theta) + (dx / dtheta) * cos(theta + dtheta);
-        a20 = -(dx / dtheta) * sin(theta) + (dx / dtheta) * sin(theta + dtheta);
+        u1 = -(dx / dtheta) * sin_t + (dx / dtheta) * sin_td;
+        u2 = (dx / dtheta) * cos_t - (dx / dtheta) * cos_td;
+        a10 = -(dx / dtheta) * cos_t + (dx / dtheta) * cos_td;
+        a20 = -(dx / dtheta) * sin_t + (dx / dtheta) * sin_td;
     }
     __syncthreads();  // all threads hold the old theta; thread 0 may now move the pose
 

@@ -246,8 +246,8 @@ struct Pool {
         if (!sigma_alt) {
             EKFC(dalloc(&sigma_alt, (size_t)pv.B * pv.sigma_stride));
             EKFC(dalloc(&state_fz, (size_t)pv.B * pv.ld));
-            EKFC(dalloc(&assoc_alt, (size_t)pv.B));
-            EKFC(dalloc(&terms, (size_t)pv.B * (pv.n > 0 ? pv.n : 1) * 16));
+            if (!assoc_alt) EKFC(dalloc(&assoc_alt, (size_t)pv.B));
+            if (!terms) EKFC(dalloc(&terms, (size_t)pv.B * (pv.n > 0 ? pv.n : 1) * 16));
             alt_synced = false;
         }
         if (!alt_synced) {
@@ -478,8 +478,9 @@ struct Pool {
     void destroy() {
         if (device >= 0) (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
+        if (assoc_block) { pv.assoc = nullptr; assoc_alt = nullptr; assoc_out_dev = nullptr; }   // (parts of the block)
         void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, pv.touch_flag, pv.touch_list,
-                        pv.touch_count, scores, meas_dev,
+                        pv.touch_count, scores, meas_dev, assoc_block,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, sigma_alt, state_fz, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
                         phase_trace, terms2, scores2, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred};
@@ -583,15 +584,39 @@ struct Pool {
         return sg.mark(stream);
     }
 
+    // Single filter: the two association records (they ping-pong between launches) and the decisions of a call live in
+    // ONE block -- [record | record | decisions] -- so that data_association() ends with one device-to-host copy.
+    char* assoc_block = nullptr;
+    static constexpr size_t kAssocRecSlot = 32, kAssocDecOff = 64;
     ekf_status ensure_meas_capacity(int J) {
         if (J <= jcap) return EKF_OK;
         HIPC(hipStreamSynchronize(stream));
         if (meas_dev) HIPC(hipFree(meas_dev));
-        if (assoc_out_dev) HIPC(hipFree(assoc_out_dev));
-        meas_dev = nullptr; assoc_out_dev = nullptr;
+        meas_dev = nullptr;
         const int cap = J < 64 ? 64 : round_up(J, 64);
         EKFC(dalloc(&meas_dev, (size_t)cap * 2));
-        EKFC(dalloc(&assoc_out_dev, (size_t)cap));
+        if (pv.B == 1) {
+            char* blk = nullptr;
+            EKFC(dalloc(&blk, kAssocDecOff + sizeof(int) * (size_t)cap));
+            HIPC(hipMemsetAsync(blk, 0, kAssocDecOff, stream));
+            // the records move in (the current one first); the old homes are released
+            HIPC(hipMemcpyAsync(blk, pv.assoc, sizeof(ekf::AssocRec), hipMemcpyDeviceToDevice, stream));
+            if (assoc_alt) HIPC(hipMemcpyAsync(blk + kAssocRecSlot, assoc_alt, sizeof(ekf::AssocRec), hipMemcpyDeviceToDevice, stream));
+            HIPC(hipStreamSynchronize(stream));
+            if (assoc_block) HIPC(hipFree(assoc_block));
+            else {
+                HIPC(hipFree(pv.assoc));
+                if (assoc_alt) HIPC(hipFree(assoc_alt));
+            }
+            assoc_block = blk;
+            pv.assoc = reinterpret_cast<ekf::AssocRec*>(blk);
+            assoc_alt = reinterpret_cast<ekf::AssocRec*>(blk + kAssocRecSlot);
+            assoc_out_dev = reinterpret_cast<int*>(blk + kAssocDecOff);
+        } else {
+            if (assoc_out_dev) HIPC(hipFree(assoc_out_dev));
+            assoc_out_dev = nullptr;
+            EKFC(dalloc(&assoc_out_dev, (size_t)cap));
+        }
         jcap = cap;
         return EKF_OK;
     }
