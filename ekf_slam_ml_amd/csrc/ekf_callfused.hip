@@ -75,6 +75,7 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
     __shared__ double sh_Kc[kCallV][kNcMax][2];          // K_v on the core rows
     __shared__ double sh_Gc[kCallV][2][kNcMax + 1];      // G_v on the core columns
     __shared__ double sh_pr[8];                          // folded prediction: a10, a20, u0, u1, u2
+    __shared__ int sh_done[4];                           // in-step hand-offs between the control waves (see below)
 
     CF_TR(0, 0); CF_TR(1, 0);
     if (src.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) src.trace[61] = __builtin_amdgcn_s_memtime();   // shader clock
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
     // block) beside the prediction folded into what this workgroup holds (wave 0: the block; the slices: their panels).
     if (wave == 1 && cnt > 0) terms_ang(0);
     if (wave == 2 && cnt > 0) terms_geo(0);
+    if (tid < 4) sh_done[tid] = tid == 2 ? 0 : 1;   // correction 0's terms are done at P2; no block update yet
     if (src.has_twist) {
         // ---- prediction(), :101-102 (the structured arithmetic of k_predict) ----
         const double a10 = sh_pr[0], a20 = sh_pr[1];
@@ -307,7 +309,10 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
     // phase 2 of a correction on wave 0: S, S^-1 (lane-parallel, the arithmetic of wave_terms_s) from the block after
     // correction v - 1, then K_v on the core and the core STATE update.  Every LDS operand is requested up front; S^-1
     // goes to LDS for the slices and stays in registers for the gains (no write -> read round trip).
-    auto core_finish = [&](int v) {
+    // core_SK(v): S, S^-1, K_v (needs H_v, nu0 and the block after correction v - 1; NOT nu1).  Leaves K_v(lane, :) and the
+    // lane's core state entry in ck0 / ck1 / cst for core_state(v), which needs the angle wave's nu1.
+    double ck0 = 0.0, ck1 = 0.0, cst = 0.0;
+    auto core_SK = [&](int v) {
         wave_sync_lds();
         const int ha = (lane / 5) & 1, hl = lane % 5;
         const int lc = lane < kNcMax ? lane : 0;
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
             H0[k] = sh_tv[v][k]; H1[k] = sh_tv[v][5 + k];
             p[k] = sh_Cb[lc][core5(k, v)];
         }
-        const double nu0 = sh_tv[v][14], nu1 = sh_tv[v][15], scv = sh_sc[lc];
+        cst = sh_sc[lc];
         double hs = 0.0;
 #pragma unroll
         for (int k = 0; k < 5; k++) hs += (ha ? H1[k] : H0[k]) * s5[k];
@@ -336,21 +341,43 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
         const double si = (sq4 == 0 ? S11 : sq4 == 1 ? -S01 : sq4 == 2 ? -S10 : S00) / det;
         if (lane < 4) sh_tv[v][10 + lane] = si;
         const double Si0 = lane_bcast(si, 0), Si1 = lane_bcast(si, 1), Si2 = lane_bcast(si, 2), Si3 = lane_bcast(si, 3);
-        if (lane < Nc) {   // lane = core row
-            double sht0 = 0.0, sht1 = 0.0;
+        double sht0 = 0.0, sht1 = 0.0;
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
-                sht0 += p[k] * H0[k];
-                sht1 += p[k] * H1[k];
-            }
-            const double k0 = sht0 * Si0 + sht1 * Si2;   // :178
-            const double k1 = sht0 * Si1 + sht1 * Si3;
-            sh_Kc[v][lane][0] = k0;
-            sh_Kc[v][lane][1] = k1;
-            double st_new = scv + (k0 * nu0 + k1 * nu1);   // core state (:186-187)
+        for (int k = 0; k < 5; k++) {
+            sht0 += p[k] * H0[k];
+            sht1 += p[k] * H1[k];
+        }
+        ck0 = sht0 * Si0 + sht1 * Si2;   // :178
+        ck1 = sht0 * Si1 + sht1 * Si3;
+        if (lane < Nc) {   // lane = core row
+            sh_Kc[v][lane][0] = ck0;
+            sh_Kc[v][lane][1] = ck1;
+        }
+    };
+    auto core_state = [&](int v) {   // core state (:186-187)
+        wave_sync_lds();
+        const double nu0 = sh_tv[v][14], nu1 = sh_tv[v][15];
+        if (lane < Nc) {
+            double st_new = cst + (ck0 * nu0 + ck1 * nu1);
             if (lane == 0) st_new = normalize_angle(st_new);
             sh_sc[lane] = st_new;
         }
+    };
+    // Hand-offs between the three control waves inside a step go through counters in LDS (sh_done[0] angle terms,
+    // [1] geometry terms, [2] block updates completed): a wave publishes after its LDS writes (DS instructions of a
+    // wave execute in order) and a waiting wave polls; every spin is bounded.  Only barrier A, which the slices need too,
+    // stays a workgroup barrier -- the slices pass ONE barrier per correction instead of two, and wave 0 no longer
+    // waits for the angle wave before S, S^-1 and K (it needs nu1 only for the last ten instructions of a correction).
+    auto publish = [&](int which, int value) {
+        wave_sync_lds();
+        if (lane == 0) __hip_atomic_store(&sh_done[which], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto await = [&](int which, int value) {
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            if (__hip_atomic_load(&sh_done[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= value) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        wave_sync_lds();
     };
     // G_v = H_v Sigma[c5(v), :] on the core columns: needs H and the updated block, not S^-1 -- wave 2, beside wave 0
     auto core_G = [&](int v) {
@@ -367,51 +394,53 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
             sh_Gc[v][1][lane] = g1;
         }
     };
-    // Four roles, each with its own loop over the corrections; every wave passes the same sequence of workgroup
-    // barriers -- P1, P2 above, then A(t) in front of step t and B(t) behind its first phase when a correction t + 1
-    // follows.  Phase 1 of step t works on correction t + 1's state-only terms (its landmark is up to date: the core state
-    // was advanced with the gains of t) beside correction t's updates; phase 2 finishes t + 1:
-    //   wave 0   phase 1: geometry of t + 1 (ranges, the quotients of H, nu0: one sqrt and one division deep);
-    //            phase 2: S, S^-1 from the updated block, the gains and the core state of t + 1
-    //   wave 1   phase 1: angles of t + 1 (the two atan2, the wraps, nu1) -- beside wave 0, not in front of it: the
-    //            per-correction chain is max(geometry, angles) + phase 2 instead of their sum
-    //   wave 2   phase 1: the core block's own rank-2 update for correction t; phase 2: G of t + 1 on the core columns
-    //   slices   phase 1: factors of correction t for their index, panels and state updated
-    // (correction 0's phase 1 ran between P1 and P2, its geometry on wave 2.)
+    // Four roles, each with its own loop over the corrections.  Every wave passes the same workgroup barriers -- P1, P2
+    // above, then A(t) in front of step t; inside a step the control waves hand over through the LDS counters.  Step t
+    // works on correction t + 1 (its landmark is up to date: the core state was advanced with the gains of t) beside
+    // correction t's updates:
+    //   wave 0   geometry of t + 1 (ranges, the quotients of H, nu0: one sqrt and one division deep) -> [block of t ready]
+    //            -> S, S^-1, K of t + 1 -> [nu1 ready] -> core state of t + 1
+    //   wave 1   angles of t + 1 (the two atan2, the wraps, nu1) -- beside wave 0, not in front of it
+    //   wave 2   the core block's own rank-2 update for correction t -> [H of t + 1 ready] -> G of t + 1 on the core columns
+    //   slices   factors of correction t for their index, panels and state updated
+    // (correction 0's state-only terms ran between P1 and P2, its geometry on wave 2.)
     // The loops of the control waves are ROLLED: their code is fetched once and then runs from the instruction cache.
     // (Unrolled eight times -- as the slices' loop must be, their panels live in statically indexed registers -- the
     // kernel was 17 k instructions of straight-line code that every workgroup fetched cold: 2.05 us per correction; rolled:
-    // 1.70 us, the chain of one wavefront at ~9 cycles per dependent fp64 instruction; with the angles on their own
-    // wave: 1.5 us.)
+    // 1.70 us, the chain of one wavefront at ~9 cycles per dependent fp64 instruction; angles on their own wave: 1.52;
+    // phase 2 trimmed: 1.44; one workgroup barrier per correction: 1.34.)
     if (wave == 0) {
-        if (cnt > 0) core_finish(0);
+        if (cnt > 0) { core_SK(0); core_state(0); }
 #pragma nounroll
         for (int t = 0; t < cnt; t++) {
-            __syncthreads();
+            __syncthreads();   // A(t)
             CF_TR(0, 3 + 5 * t);
             if (t + 1 < cnt) {
                 terms_geo(t + 1);
+                publish(1, t + 2);
                 CF_TR(0, 4 + 5 * t);
-                __syncthreads();
+                await(2, t + 1);          // the block after correction t
                 CF_TR(0, 5 + 5 * t);
-                core_finish(t + 1);
+                core_SK(t + 1);
+                await(0, t + 2);          // nu1 of correction t + 1
+                core_state(t + 1);
                 CF_TR(0, 6 + 5 * t);
             }
         }
     } else if (wave == 1) {
 #pragma nounroll
         for (int t = 0; t < cnt; t++) {
-            __syncthreads();
+            __syncthreads();   // A(t)
             if (t + 1 < cnt) {
                 terms_ang(t + 1);
-                __syncthreads();
+                publish(0, t + 2);
             }
         }
     } else if (wave == 2) {
         if (cnt > 0) core_G(0);
 #pragma nounroll
         for (int t = 0; t < cnt; t++) {
-            __syncthreads();
+            __syncthreads();   // A(t)
             // the core block's own rank-2 update (:191-192); compile-time divisor, positions beyond Nc hold zero factors
 #pragma unroll
             for (int q = 0; q < (kNcMax * kNcMax + 63) / 64; q++) {
@@ -420,7 +449,8 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
                 if (j < Nc && c < Nc)
                     sh_Cb[j][c] = sh_Cb[j][c] - (sh_Kc[t][j][0] * sh_Gc[t][0][c] + sh_Kc[t][j][1] * sh_Gc[t][1][c]);
             }
-            if (t + 1 < cnt) { __syncthreads(); core_G(t + 1); }
+            publish(2, t + 1);
+            if (t + 1 < cnt) { await(1, t + 2); core_G(t + 1); }   // (H of correction t + 1 from wave 0)
         }
     } else {
 #pragma unroll
@@ -466,7 +496,6 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
             st_i = st_i + (k0 * sh_tv[v][14] + k1 * sh_tv[v][15]);   // :186
             if (i == 0) st_i = normalize_angle(st_i);                 // :187
             CF_TR(1, 4 + 5 * t);
-            if (t + 1 < cnt) __syncthreads();   // uniform
           }
         }
     }

@@ -247,6 +247,26 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     auto posB = [](int k) { return k < 3 ? k : k + 2; };
 
     const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    // The lane's base entries Sigma(r, C[k]) and Sigma(C[k], r) are requested FIRST: they depend on nothing but the two
+    // landmarks, and the workgroup's latency-bound prologue below (core block, the two corrections' terms on one lane,
+    // three barriers: a tenth of a workgroup's life) then runs while they are in flight.
+    const bool row_live = r < N;
+    const bool two = r + 1 < N;  // N is odd: the last lane owns one real index and one pad index
+    double2_t p[7], g[7];        // Sigma(r, C[k]) and Sigma(C[k], r) for r and r + 1
+    if (row_live) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const int c = cidx(k);
+            g[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)c * ld + r);
+            if (pend.symmetric) {
+                p[k] = g[k];
+                if (!two) p[k].y = 0.0;
+            } else {
+                p[k].x = Sg[(size_t)r * ld + c];
+                p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
+            }
+        }
+    }
     for (int idx = tid; idx < 7 * rc; idx += 256) {
         const int k = idx / rc, j = idx - k * rc;
         const int c = cidx(k);
@@ -330,21 +350,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
 
     double2_t k1a = zero2, k1b = zero2, g1a = zero2, g1b = zero2, k2a = zero2, k2b = zero2, g2a = zero2, g2b = zero2;
     double2_t snew = zero2;
-    if (r < N) {
-        const bool two = r + 1 < N;  // N is odd: the last lane owns one real index and one pad index
-        double2_t p[7], g[7];        // Sigma(r, C[k]) and Sigma(C[k], r) for r and r + 1
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-            const int c = cidx(k);
-            g[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)c * ld + r);
-            if (pend.symmetric) {
-                p[k] = g[k];
-                if (!two) p[k].y = 0.0;
-            } else {
-                p[k].x = Sg[(size_t)r * ld + c];
-                p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
-            }
-        }
+    if (row_live) {
         auto ld4 = [&](int j, double2_t& a0, double2_t& a1, double2_t& b0, double2_t& b1) {
             a0 = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
             a1 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
