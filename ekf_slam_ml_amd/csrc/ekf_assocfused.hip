@@ -406,6 +406,362 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
 #undef AR_TR
 }
 
+// ---------------------------------------------------------------------------------------------
+// A WHOLE data_association() call (<= kCallV readings) of a single filter in ONE launch, while the discovered part of
+// the map fits one workgroup: thread t carries landmark t -- its 5 x 5 block of Sigma, its position and its two state
+// indices -- in registers from the first reading of the call to the last; a helper wave carries the pose.  Per reading:
+// score (no memory access: the block is kept CURRENT by folding each new pair into it, instead of re-gathering it and
+// re-applying every pending pair), reduction + decision, one round trip for Sigma(r, c5(lm)) / Sigma(c5(lm), r), gain,
+// pair appended, block updated.  The pass over Sigma (k_rank2v) follows as a second launch: two launches per CALL where the
+// per-reading forms take two per READING.  Same operations in the same order as the other forms (a landmark that is not
+// discovered yet has K = G = 0 exactly, so folding the pairs into its block from the start leaves it bit-identical).
+// ---------------------------------------------------------------------------------------------
+// two doubles at an 8-byte-aligned address (a thread's indices 3 + 2t, 4 + 2t; the columns 3 + 2 lm, 4 + 2 lm of a row)
+struct __attribute__((packed, aligned(8))) D2u { double x, y; };
+
+constexpr int kCallLandmarks = 448;   // landmarks one workgroup carries: 7 wavefronts + the helper wave = 512 threads
+
+// THREADS: 256 (up to 192 landmarks: one wave per SIMD, the whole register file -- four pending pairs' values requested with
+// the gathers) or 512 (up to 448: requested behind them, four at a time)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_assoc_call(PoolView pv, AssocCallArgs a, int* __restrict__ assoc_out,
+                                                                    double* __restrict__ Uall, double* __restrict__ Vall,
+                                                                    int* __restrict__ cnt_out, int zero_upto,
+                                                                    long long* __restrict__ trace) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    // diagnostics (ekf_phase_trace): thread 0 stamps the 100 MHz wall clock, 16 slots per reading (slot 15 of reading 0: start)
+#define AC_TR(j, k) do { if (trace && tid == 0) trace[(j) * 16 + (k)] = wall_clock64(); } while (0)
+    AC_TR(0, 15);
+    const int nmain = (int)blockDim.x - 64;
+    const bool helper = tid >= nmain;
+    const int hl = tid - nmain;
+    const int n = pv.n, N = pv.N, ld = pv.ld;
+    const double* __restrict__ Sg = pv.sigma;
+    double* st = pv.state;   // (updated in place: one workgroup, ordered by its barriers)
+    double* Ub = Uall;
+    double* Vb = Vall;
+    const int J = a.J;
+    // the state indices this thread owns: main thread t -> 3 + 2t, 4 + 2t; helper lanes 0..2 -> the pose
+    const int t = tid;
+    const bool has_lm = !helper && t < n;
+    const int nown = helper ? (hl < 3 ? 1 : 0) : (has_lm ? 2 : 0);
+    const int r0 = helper ? (hl < 3 ? hl : 0) : (has_lm ? 3 + 2 * t : 0);
+
+    constexpr int kPre = THREADS <= 256 ? kCallV - 1 : 0;
+    constexpr int kBatch = THREADS <= 256 ? 4 : 2;
+    __shared__ double sh_d[THREADS / 64];
+    __shared__ int sh_i[THREADS / 64];
+    __shared__ int sh_M, sh_lm, sh_new;
+    __shared__ double sh_t[2];
+    __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
+    __shared__ double sh_K5[kCallV][5][2], sh_G5[kCallV][5][2];
+    __shared__ double sh_pose[3], sh_z[kCallV][2];
+    __shared__ double sh_terms[THREADS - 64][17];   // H, S^-1, nu of every scored landmark (the winner's are needed)
+
+    // ---- the call's inputs: block, position, pose, the readings in polar form (one lane each) ----
+    double S55[5][5], pos[2] = {0.0, 0.0};
+    if (has_lm) {
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int l = 0; l < 5; l++) S55[k][l] = Sg[(size_t)idx5(k, t) * ld + idx5(l, t)];
+        pos[0] = st[r0]; pos[1] = st[r0 + 1];
+    }
+    // Sigma(r, 0..2) and Sigma(0..2, r) of the owned indices: the stored covariance does not change during the call (the pairs
+    // stay pending), and every correction gathers the pose's three rows and columns -- fetched once, kept in registers
+    const int rb = nown > 0 ? r0 : 0;            // (threads without an index gather from row / column 0: never used)
+    const int rb1 = nown > 1 ? r0 + 1 : rb;
+    // (the 512-thread form has no registers to spare for it and gathers them per reading)
+    constexpr bool kPosePanel = THREADS <= 256;
+    double pp[2][3], gp[2][3];
+    auto pose_panel = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const double* row = Sg + (size_t)(q ? rb1 : rb) * ld;
+            const D2u c01 = *reinterpret_cast<const D2u*>(row);
+            pp[q][0] = c01.x; pp[q][1] = c01.y; pp[q][2] = row[2];
+        }
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) {
+            const D2u gg = *reinterpret_cast<const D2u*>(Sg + (size_t)k3 * ld + rb);
+            gp[0][k3] = gg.x; gp[1][k3] = gg.y;
+        }
+    };
+    if constexpr (kPosePanel) pose_panel();
+    if (helper && hl < 3) { pos[0] = st[hl]; sh_pose[hl] = pos[0]; }
+    if (helper && hl >= 8 && hl < 8 + J) {
+        const double mx = a.xy[hl - 8][0], my = a.xy[hl - 8][1];
+        sh_z[hl - 8][0] = sqrt(mx * mx + my * my);   // :142-146
+        sh_z[hl - 8][1] = atan2(my, mx);
+    }
+    if (tid == 0) { sh_M = pv.assoc[0].known_count; sh_lm = -1; }
+    __syncthreads();
+
+    int pc = 0;   // pairs appended so far (uniform)
+    for (int j = 0; j < J; j++) {   // :291 sequential, state-carrying
+        const double mx = a.xy[j][0], my = a.xy[j][1];
+        const int M = sh_M;
+        const double theta = sh_pose[0], x = sh_pose[1], y = sh_pose[2];   // fresh pose per reading, :219-221 / :331-333
+        AC_TR(j, 0);
+        // ---- score, :300-309: this thread's landmark, everything in registers ----
+        double best = pv.p.gate_new;  // :293
+        int bi = INT_MAX;
+        if (has_lm && t < M) {
+            MeasTerms m;
+            m.z0 = sh_z[j][0]; m.z1 = sh_z[j][1];
+            predicted_terms(pos[0], pos[1], theta, x, y, m);
+            double S[2][2], Si[2][2];
+            innovation_cov(S55, m.H, pv.p.r_meas, S);   // sums in the order of k_maha's shuffle folds
+            inv2(S, Si);
+            const double v0 = m.z0 - m.zh0, v1 = m.z1 - m.zh1;   // bearing NOT wrapped, :269
+            const double t0 = v0 * Si[0][0] + v1 * Si[1][0];
+            const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
+            const double sc = t0 * v0 + t1 * v1;
+            if (sc < best) { best = sc; bi = t; }   // :305-309 (NaN never wins)
+            double* tr = sh_terms[t];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { tr[k] = m.H[0][k]; tr[5 + k] = m.H[1][k]; }
+            tr[10] = Si[0][0]; tr[11] = Si[0][1]; tr[12] = Si[1][0]; tr[13] = Si[1][1];
+            tr[14] = v0; tr[15] = v1;
+        }
+        AC_TR(j, 1);
+        // lexicographic (d, i) minimum = the sequential scan's first strict minimum
+        double rd = best;
+        int ri = bi;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_down(rd, off, kWave);
+            const int oi = __shfl_down(ri, off, kWave);
+            if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
+        }
+        if (lane == 0) { sh_d[tid >> 6] = rd; sh_i[tid >> 6] = ri; }
+        __syncthreads();
+        AC_TR(j, 2);
+        if (tid == 0) {   // :293-330
+            for (int w = 1; w < (int)blockDim.x / 64; w++)
+                if (sh_d[w] < rd || (sh_d[w] == rd && sh_i[w] < ri)) { rd = sh_d[w]; ri = sh_i[w]; }
+            const int idx = (ri == INT_MAX) ? M : ri;   // :294 min_maha_idx = known_count
+            int Mn = M, is_new = 0;
+            if (idx == M && idx < n) {                  // :318-327 new landmark
+                const double rr = sqrt(mx * mx + my * my);
+                const double phi = atan2(my, mx);
+                sh_t[0] = x + rr * cos(phi + theta);
+                sh_t[1] = y + rr * sin(phi + theta);
+                Mn = M + 1;
+                rd = 0.0;
+                is_new = 1;
+            }
+            const int active = (rd < pv.p.gate_update) && idx < n;   // :330
+            sh_M = Mn;
+            sh_lm = active ? idx : -1;
+            sh_new = is_new;
+            assoc_out[j] = active ? idx : -1;
+        }
+        __syncthreads();
+        AC_TR(j, 3);
+        const int lm = sh_lm;
+        const int is_new = sh_new;
+        if (lm < 0) { __syncthreads(); continue; }   // dropped (uniform); the barrier keeps sh_lm stable for slow waves
+        // ---- requests: Sigma(r, c5(lm)) and Sigma(c5(lm), r) for the owned indices; the pairs' values at the winner ----
+        // the active dimension of this reading (landmarks are appended in discovery order, :318-327): K, G are exact zeros beyond
+        int mact = a.known_count + j + 1 < n ? a.known_count + j + 1 : n;
+        if (a.touched_hwm > mact) mact = a.touched_hwm;
+        const int Nb = a.active_prefix ? 3 + 2 * mact : N;
+        // Wide accesses: a thread's two indices are neighbours, and so are the columns {3 + 2 lm, 4 + 2 lm} of a row --
+        // 16-byte loads (8-byte aligned) fetch two entries each.  A column gather costs the memory pipe one request per
+        // lane and instruction whatever its width: 4 instructions per reading here instead of 20.
+        double p[2][5], g[2][5];
+        if constexpr (!kPosePanel) pose_panel();
+        {
+            const size_t cl = 3 + 2 * (size_t)lm;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const double* row = Sg + (size_t)(q ? rb1 : rb) * ld;   // Sigma(r, c5(lm)): column gather (Sigma * H^T)
+                const D2u cll = *reinterpret_cast<const D2u*>(row + cl);
+                p[q][0] = pp[q][0]; p[q][1] = pp[q][1]; p[q][2] = pp[q][2]; p[q][3] = cll.x; p[q][4] = cll.y;
+            }
+#pragma unroll
+            for (int k = 3; k < 5; k++) {                                // Sigma(c5(lm), r): row gather (H * Sigma)
+                const D2u gg = *reinterpret_cast<const D2u*>(Sg + (size_t)idx5(k, lm) * ld + rb);
+                g[0][k] = gg.x; g[1][k] = gg.y;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { g[0][k] = gp[0][k]; g[1][k] = gp[1][k]; }
+        }
+        // ... and the pending pairs' values at the owned indices (the first kPre pairs: one round trip with the gathers;
+        // later pairs take one more per four)
+        D2u f0[kPre > 0 ? kPre : 1][4];
+#pragma unroll
+        for (int v = 0; v < kPre; v++) {
+            const int vc = v < pc ? v : 0;
+            f0[v][0] = *reinterpret_cast<const D2u*>(Ub + (size_t)(2 * vc) * ld + rb);
+            f0[v][1] = *reinterpret_cast<const D2u*>(Ub + (size_t)(2 * vc + 1) * ld + rb);
+            f0[v][2] = *reinterpret_cast<const D2u*>(Vb + (size_t)(2 * vc) * ld + rb);
+            f0[v][3] = *reinterpret_cast<const D2u*>(Vb + (size_t)(2 * vc + 1) * ld + rb);
+        }
+        if (tid < 4 * pc) {
+            const int v = tid >> 2, q = (tid >> 1) & 1, h = tid & 1;
+            sh_K5[v][3 + q][h] = Ub[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
+            sh_G5[v][3 + q][h] = Vb[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
+        }
+        // ---- the winner's H, S^-1, nu: from the thread that carries the landmark ----
+        if (has_lm && t == lm) {
+            if (is_new) {   // :331-381 with the fresh pose: the landmark this reading has just initialised (:321-322)
+                pos[0] = sh_t[0]; pos[1] = sh_t[1];
+                MeasTerms m;
+                m.z0 = sh_z[j][0]; m.z1 = sh_z[j][1];
+                predicted_terms(pos[0], pos[1], theta, x, y, m);
+                double S[2][2], Si[2][2];
+                innovation_cov(S55, m.H, pv.p.r_meas, S);
+                inv2(S, Si);
+                for (int k = 0; k < 5; k++) { sh_H[k] = m.H[0][k]; sh_H[5 + k] = m.H[1][k]; }
+                sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
+                sh_nu[0] = m.z0 - m.zh0;
+                sh_nu[1] = normalize_angle(m.z1 - m.zh1);
+            }
+        }
+        if (!is_new && tid < 16) {   // as the landmark's thread left them when it scored
+            const double tv = sh_terms[lm][tid];
+            if (tid < 10) sh_H[tid] = tv;
+            else if (tid < 14) sh_Si[tid - 10] = tv;
+            else if (tid == 14) sh_nu[0] = tv;
+            else sh_nu[1] = normalize_angle(tv);   // :183 (the score used it unwrapped)
+        }
+        AC_TR(j, 4);
+        __syncthreads();
+        AC_TR(j, 5);
+        // ---- K = Sigma H^T S^-1 (:376), G = H Sigma at the owned indices; pair pc; state ----
+        double kq[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, gq[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        // ... as they stand now: minus the pending pairs, in order
+        auto fold_rc = [&](int v, const D2u (&f)[4]) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                p[0][k] = p[0][k] - (f[0].x * sh_G5[v][k][0] + f[1].x * sh_G5[v][k][1]);
+                g[0][k] = g[0][k] - (sh_K5[v][k][0] * f[2].x + sh_K5[v][k][1] * f[3].x);
+                p[1][k] = p[1][k] - (f[0].y * sh_G5[v][k][0] + f[1].y * sh_G5[v][k][1]);
+                g[1][k] = g[1][k] - (sh_K5[v][k][0] * f[2].y + sh_K5[v][k][1] * f[3].y);
+            }
+        };
+        auto load_rc = [&](int v, D2u (&f)[4]) {
+            f[0] = *reinterpret_cast<const D2u*>(Ub + (size_t)(2 * v) * ld + rb);
+            f[1] = *reinterpret_cast<const D2u*>(Ub + (size_t)(2 * v + 1) * ld + rb);
+            f[2] = *reinterpret_cast<const D2u*>(Vb + (size_t)(2 * v) * ld + rb);
+            f[3] = *reinterpret_cast<const D2u*>(Vb + (size_t)(2 * v + 1) * ld + rb);
+        };
+        if (nown > 0) {
+#pragma unroll
+            for (int v = 0; v < kPre; v++)
+                if (v < pc) fold_rc(v, f0[v]);   // (uniform)
+            int v = kPre;
+            for (; v + kBatch <= pc; v += kBatch) {   // (kBatch pairs' values requested together)
+                D2u f[kBatch][4];
+#pragma unroll
+                for (int w = 0; w < kBatch; w++) load_rc(v + w, f[w]);
+#pragma unroll
+                for (int w = 0; w < kBatch; w++) fold_rc(v + w, f[w]);
+            }
+            for (; v < pc; v++) {
+                D2u f[4];
+                load_rc(v, f);
+                fold_rc(v, f);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int r = r0 + q;
+            if (q < nown && r < Nb) {
+                double sht0 = 0.0, sht1 = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    sht0 += p[q][k] * sh_H[k];
+                    sht1 += p[q][k] * sh_H[5 + k];
+                    g0 += sh_H[k] * g[q][k];
+                    g1 += sh_H[5 + k] * g[q][k];
+                }
+                kq[q][0] = sht0 * sh_Si[0] + sht1 * sh_Si[2];   // :376
+                kq[q][1] = sht0 * sh_Si[1] + sht1 * sh_Si[3];
+                gq[q][0] = g0; gq[q][1] = g1;
+                double sv = pos[q] + (kq[q][0] * sh_nu[0] + kq[q][1] * sh_nu[1]);   // :384
+                if (r == 0) sv = normalize_angle(sv);                                  // :385
+                pos[q] = sv;
+            }
+        }
+        if (nown == 2) {   // the new pair at the thread's two (neighbouring) indices: 16-byte stores
+            *reinterpret_cast<D2u*>(Ub + (size_t)(2 * pc) * ld + r0) = D2u{kq[0][0], kq[1][0]};
+            *reinterpret_cast<D2u*>(Ub + (size_t)(2 * pc + 1) * ld + r0) = D2u{kq[0][1], kq[1][1]};
+            *reinterpret_cast<D2u*>(Vb + (size_t)(2 * pc) * ld + r0) = D2u{gq[0][0], gq[1][0]};
+            *reinterpret_cast<D2u*>(Vb + (size_t)(2 * pc + 1) * ld + r0) = D2u{gq[0][1], gq[1][1]};
+        } else if (nown == 1) {
+            Ub[(size_t)(2 * pc) * ld + r0] = kq[0][0]; Ub[(size_t)(2 * pc + 1) * ld + r0] = kq[0][1];
+            Vb[(size_t)(2 * pc) * ld + r0] = gq[0][0]; Vb[(size_t)(2 * pc + 1) * ld + r0] = gq[0][1];
+        }
+        if (helper && hl < 3) {   // pose part of the new pair, and the pose the next reading sees
+            sh_K5[pc][hl][0] = kq[0][0]; sh_K5[pc][hl][1] = kq[0][1]; sh_G5[pc][hl][0] = gq[0][0]; sh_G5[pc][hl][1] = gq[0][1];
+            sh_pose[hl] = pos[0];
+        }
+        AC_TR(j, 6);
+        __syncthreads();
+        AC_TR(j, 7);
+        // ---- the landmark's block takes the new pair (k_rank2's expression): it stays current for the next reading ----
+        if (has_lm) {
+            double kr[5][2], gc[5][2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { kr[k][0] = sh_K5[pc][k][0]; kr[k][1] = sh_K5[pc][k][1]; gc[k][0] = sh_G5[pc][k][0]; gc[k][1] = sh_G5[pc][k][1]; }
+#pragma unroll
+            for (int q = 0; q < 2; q++) { kr[3 + q][0] = kq[q][0]; kr[3 + q][1] = kq[q][1]; gc[3 + q][0] = gq[q][0]; gc[3 + q][1] = gq[q][1]; }
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+#pragma unroll
+                for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
+        }
+        pc++;
+        AC_TR(j, 8);
+    }
+#undef AC_TR
+    // ---- the call's results: state, pair rows the pass does not use, records ----
+    for (int q = 0; q < nown; q++) st[r0 + q] = pos[q];
+    for (int r = tid; r < ld; r += (int)blockDim.x)
+        for (int v = pc; v < zero_upto; v++) {
+            Ub[(size_t)(2 * v) * ld + r] = 0.0; Ub[(size_t)(2 * v + 1) * ld + r] = 0.0;
+            Vb[(size_t)(2 * v) * ld + r] = 0.0; Vb[(size_t)(2 * v + 1) * ld + r] = 0.0;
+        }
+    // (pair rows of indices no thread owns -- beyond the carried landmarks -- are exact zeros)
+    for (int r = 3 + 2 * min(nmain, n) + tid; r < ld; r += (int)blockDim.x)
+        for (int v = 0; v < pc; v++) {
+            Ub[(size_t)(2 * v) * ld + r] = 0.0; Ub[(size_t)(2 * v + 1) * ld + r] = 0.0;
+            Vb[(size_t)(2 * v) * ld + r] = 0.0; Vb[(size_t)(2 * v + 1) * ld + r] = 0.0;
+        }
+    const int Mend = sh_M;
+    if (has_lm && t < Mend) {   // touched-set bookkeeping: every landmark below the known count counts as touched
+        unsigned char* tf = pv.touch_flag;
+        if (!tf[t]) {
+            tf[t] = 1;
+            const int slot = atomicAdd(&pv.touch_count[0], 1);
+            pv.touch_list[slot] = t;
+        }
+    }
+    if (tid == 0) {
+        cnt_out[0] = pc;
+        AssocRec rec;
+        rec.known_count = Mend; rec.lm = sh_lm; rec.active = sh_lm >= 0; rec.pad = 0; rec.best = 0.0;
+        pv.assoc[0] = rec;
+        CorrRec rc;
+        rc.nu0 = 0.0; rc.nu1 = 0.0; rc.active = sh_lm >= 0; rc.lm = sh_lm; rc.n_active = 0; rc.pad = 0;
+        pv.rec[0] = rc;
+    }
+}
+
+int assoc_call_capacity() { return kCallLandmarks; }
+
+void launch_assoc_call(const PoolView& pv, const AssocCallArgs& a, int carried, int* assoc_out, double* U, double* V,
+                       int* cnt_out, int zero_upto, hipStream_t s, long long* trace) {
+    const int waves = (carried + 63) / 64 > 0 ? (carried + 63) / 64 : 1;
+    if (waves <= 3)
+        hipLaunchKernelGGL(k_assoc_call<256>, dim3(1), dim3(64 * waves + 64), 0, s, pv, a, assoc_out, U, V, cnt_out, zero_upto, trace);
+    else
+        hipLaunchKernelGGL(k_assoc_call<512>, dim3(1), dim3(64 * waves + 64), 0, s, pv, a, assoc_out, U, V, cnt_out, zero_upto, trace);
+}
+
 void launch_assoc_score(const PoolView& pv, double mx, double my, const AssocRec* assoc_in, const double* U, const double* V,
                         int pc, int m_bound, double* scores, double* terms, hipStream_t s) {
     if (m_bound > 0)

@@ -301,6 +301,38 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         if (P.touched_hwm > m) m = P.touched_hwm;
         return 3 + 2 * m;
     };
+    // The discovered map fits one workgroup (known_count + J and every landmark ever corrected <= 448): the whole call is
+    // ONE launch -- a thread per landmark keeps its 5 x 5 block of Sigma current in registers from the first reading to the
+    // last (ekf_assocfused.hip: k_assoc_call) -- plus one pass over the prefix.  configs[2]'s discovery run: two launches
+    // per call where the per-reading forms take two per reading.
+    {
+        int carried = known_count + J < n ? known_count + J : n;
+        if (P.touched_hwm > carried) carried = P.touched_hwm;
+        if (!delayed && P.pv.B == 1 && P.call_fused_ok() && carried <= ekf::assoc_call_capacity()) {
+            EKFC(P.ensure_callfused());
+            P.alt_synced = false;
+            for (int j0 = 0; j0 < J; j0 += ekf::kCallV) {
+                const int jc = J - j0 < ekf::kCallV ? J - j0 : ekf::kCallV;
+                ekf::AssocCallArgs ca{};
+                for (int jj = 0; jj < jc; jj++) { ca.xy[jj][0] = meas_xy[2 * (j0 + jj)]; ca.xy[jj][1] = meas_xy[2 * (j0 + jj) + 1]; }
+                ca.J = jc;
+                ca.known_count = known_count + j0 < n ? known_count + j0 : n;
+                ca.touched_hwm = P.touched_hwm;
+                ca.active_prefix = P.active_prefix;
+                EKFC(P.prof_begin(1));
+                ekf::launch_assoc_call(P.pv, ca, carried, P.assoc_out_dev + j0, P.cf_U, P.cf_V, P.cf_cnt, ekf::rank2v_round_count(jc),
+                                       P.stream, P.phase_trace);
+                EKFC(P.prof_end());
+                ekf::PoolView view = P.pv;
+                view.N = active_dim(j0 + jc - 1);
+                EKFC(P.prof_begin(0));
+                ekf::launch_rank2v(view, P.cf_U, P.cf_V, P.cf_cnt, jc, P.tuning, P.stream);
+                EKFC(P.prof_end());
+            }
+            EKFC(checked_launch());
+            return associate_finish(P, known_count, J, known, assoc_out);
+        }
+    }
     // Big discovered prefixes (>= 1400: from ~15 MB of covariance per reading): scores / decision + gain against the stored
     // covariance minus the call's pending pairs (two small launches per reading) and ONE pass over Sigma per call (per 8
     // readings) -- ekf_assocfused.hip; bit-identical.  Measured at n = 1000, known = 1000 (tools/assoc_bench.py):

@@ -500,6 +500,20 @@ void launch_assoc_reading(const PoolView& pv, double mx, double my, int has_next
                           double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound, const double* scores,
                           const double* terms, double* scores_out, double* terms_out, hipStream_t s,
                           long long* trace = nullptr);
+// A whole data_association() call (<= kCallV readings) of a single filter in ONE launch while the discovered part of the
+// map fits one workgroup (`carried` >= max(known_count + J, touched_hwm) landmarks, <= assoc_call_capacity()): a thread per
+// landmark keeps its block of Sigma current in registers.  In place on pv.state / pv.assoc; the pairs go to U / V, the caller
+// ends the call with launch_rank2v.
+struct AssocCallArgs {
+    double xy[kCallV][2];   // the readings, by value
+    int J;
+    int known_count;        // host's known count in front of the call (= the device's)
+    int touched_hwm;        // landmarks below it may carry non-constructor covariance
+    int active_prefix;      // 1: corrections confined to the discovered prefix
+};
+int assoc_call_capacity();
+void launch_assoc_call(const PoolView& pv, const AssocCallArgs& a, int carried, int* assoc_out, double* U, double* V,
+                       int* cnt_out, int zero_upto, hipStream_t s, long long* trace = nullptr);
 int rank2v_round_count(int vcount);   // corrections per pass, rounded up to an instantiated count of k_rank2v
 
 // one step of an unknown-association log for every filter of a pool in ONE launch, any prefix size (ekf_stepfused.hip):
