@@ -294,12 +294,9 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
     if (corr) {   // (uniform)
         // Sigma(r, c5(lm)) and Sigma(c5(lm), r): requested before anything else waits
         double p[5], g[5];
+        gather_row5(Sg + (size_t)rl * ld, lm, p);   // column gather (Sigma * H^T reads columns): three loads
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int c = idx5(k, lm);
-            p[k] = Sg[(size_t)rl * ld + c];   // column gather (Sigma * H^T reads columns)
-            g[k] = Sg[(size_t)c * ld + rl];   // row gather    (H * Sigma reads rows)
-        }
+        for (int k = 0; k < 5; k++) g[k] = Sg[(size_t)idx5(k, lm) * ld + rl];   // row gather (H * Sigma reads rows)
         // pending pairs at the winner's two indices; the winner's terms (from the thread that scored it, or built for a new
         // one): requested into registers, stored to LDS behind the block update, which runs while they are in flight
         double wk = 0.0, wg = 0.0, tv = 0.0;
@@ -416,9 +413,6 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
 // per-reading forms take two per READING.  Same operations in the same order as the other forms (a landmark that is not
 // discovered yet has K = G = 0 exactly, so folding the pairs into its block from the start leaves it bit-identical).
 // ---------------------------------------------------------------------------------------------
-// two doubles at an 8-byte-aligned address (a thread's indices 3 + 2t, 4 + 2t; the columns 3 + 2 lm, 4 + 2 lm of a row)
-struct __attribute__((packed, aligned(8))) D2u { double x, y; };
-
 constexpr int kCallLandmarks = 448;   // landmarks one workgroup carries: 7 wavefronts + the helper wave = 512 threads
 
 // THREADS: 256 (up to 192 landmarks: one wave per SIMD, the whole register file -- four pending pairs' values requested with

@@ -147,10 +147,17 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
         // panels: slice thread s carries column i of Sigma[C, :] and row i of Sigma[:, C], i = slice base + s
         const int ic = live ? i : 0;
 #pragma unroll
-        for (int j = 0; j < kNcMax; j++) {   // unconditional, clamped: 2 x 19 loads in flight, one round trip
-            const int cj = cidx(j);
-            Rcol[j] = Sg[(size_t)cj * ld + ic];   // coalesced across the slice
-            Crow[j] = Sg[(size_t)ic * ld + cj];   // one or two sectors of row i per landmark
+        for (int j = 0; j < kNcMax; j++)   // unconditional, clamped: all loads in flight together, one round trip
+            Rcol[j] = Sg[(size_t)cidx(j) * ld + ic];   // coalesced across the slice
+        {   // row i at the core columns: {0, 1}, {2}, and one 16-byte access per landmark (its two columns are neighbours)
+            const double* rowi = Sg + (size_t)ic * ld;
+            const D2u c01 = *reinterpret_cast<const D2u*>(rowi);
+            Crow[0] = c01.x; Crow[1] = c01.y; Crow[2] = rowi[2];
+#pragma unroll
+            for (int v = 0; v < kCallV; v++) {
+                const D2u cl = *reinterpret_cast<const D2u*>(rowi + cidx(3 + 2 * v));
+                Crow[3 + 2 * v] = cl.x; Crow[4 + 2 * v] = cl.y;
+            }
         }
         st_i = st[ic];
 #pragma unroll

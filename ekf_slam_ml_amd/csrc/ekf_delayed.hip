@@ -261,9 +261,20 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
             if (pend.symmetric) {
                 p[k] = g[k];
                 if (!two) p[k].y = 0.0;
-            } else {
-                p[k].x = Sg[(size_t)r * ld + c];
-                p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
+            }
+        }
+        if (!pend.symmetric) {
+            // the seven column entries of a row as four loads: {0, 1}, {2}, and the two landmarks' neighbouring pairs
+            const double* rw0 = Sg + (size_t)r * ld;
+            const double* rw1 = Sg + (size_t)(two ? r + 1 : r) * ld;
+            const D2u a0 = *reinterpret_cast<const D2u*>(rw0), a1 = *reinterpret_cast<const D2u*>(rw1);
+            const D2u b0 = *reinterpret_cast<const D2u*>(rw0 + cidx(3)), b1 = *reinterpret_cast<const D2u*>(rw1 + cidx(3));
+            const D2u c0 = *reinterpret_cast<const D2u*>(rw0 + cidx(5)), c1 = *reinterpret_cast<const D2u*>(rw1 + cidx(5));
+            p[0].x = a0.x; p[1].x = a0.y; p[2].x = rw0[2]; p[3].x = b0.x; p[4].x = b0.y; p[5].x = c0.x; p[6].x = c0.y;
+            p[0].y = a1.x; p[1].y = a1.y; p[2].y = rw1[2]; p[3].y = b1.x; p[4].y = b1.y; p[5].y = c1.x; p[6].y = c1.y;
+            if (!two) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) p[k].y = 0.0;
             }
         }
     }

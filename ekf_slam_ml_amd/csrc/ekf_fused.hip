@@ -83,8 +83,7 @@ __global__ __launch_bounds__(256) void k_correct_fused(PoolView pv, CmdSrc src, 
     double p[5];
     const int kr = row_begin + tid;
     if (kr < row_end) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) p[k] = cur[(size_t)kr * ld + idx5(k, lm)];       // columns of Sigma*H^T
+        gather_row5(cur + (size_t)kr * ld, lm, p);                                   // columns of Sigma*H^T: three loads
     }
     if (tid < 25) sh_S55[tid] = cur[(size_t)idx5(tid / 5, lm) * ld + idx5(tid % 5, lm)];
     double theta = 0.0, x = 0.0, y = 0.0, tx = 0.0, ty = 0.0;
@@ -281,8 +280,7 @@ __global__ __launch_bounds__(256) void k_associate_fused(PoolView pv, MeasSrc ms
     double p[5];
     const int kr = row_begin + tid;
     if (kr < row_end) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) p[k] = cur[(size_t)kr * ld + idx5(k, lm)];
+        gather_row5(cur + (size_t)kr * ld, lm, p);
     }
     if (is_new || !ms.terms) {  // no record from k_maha: build H, S^-1, nu from the 5x5 block (uniform branch)
         if (tid < 25) sh_S55[tid] = cur[(size_t)idx5(tid / 5, lm) * ld + idx5(tid % 5, lm)];

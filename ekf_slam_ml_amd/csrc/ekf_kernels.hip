@@ -261,12 +261,13 @@ __global__ __launch_bounds__(256) void k_gain(PoolView pv, CmdSrc src) {
     const bool krow = r < N && (!pv.active_set || r < 3 || ((r - 3) >> 1) == lm ||
                                 pv.touch_flag[(size_t)b * pv.n + ((r - 3) >> 1)]);
     if (r < N) {
+        if (krow) gather_row5(Sg + (size_t)r * ld, lm, p);   // column gather (Sigma * H^T reads columns): three loads
+        else {
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int c = idx5(k, lm);
-            p[k] = krow ? Sg[(size_t)r * ld + c] : 0.0;  // column gather (Sigma * H^T reads columns)
-            g[k] = Sg[(size_t)c * ld + r];               // row gather    (H * Sigma reads rows)
+            for (int k = 0; k < 5; k++) p[k] = 0.0;
         }
+#pragma unroll
+        for (int k = 0; k < 5; k++) g[k] = Sg[(size_t)idx5(k, lm) * ld + r];   // row gather (H * Sigma reads rows)
     }
     if (tid < 25) sh_S55[tid] = Sg[(size_t)idx5(tid / 5, lm) * ld + idx5(tid % 5, lm)];
     double theta = 0.0, x = 0.0, y = 0.0, tx = 0.0, ty = 0.0;

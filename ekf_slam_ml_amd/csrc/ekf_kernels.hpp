@@ -23,6 +23,15 @@ constexpr double kPI = 3.14159265358979323846;  // rigid2d/include/rigid2d/rigid
 constexpr int kWave = 64;
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
+// Two doubles at an 8-byte-aligned address, fetched by ONE 16-byte access: the columns {3 + 2i, 4 + 2i} of a row (3 + 2i is
+// odd), a thread's indices {3 + 2t, 4 + 2t}.  A column gather costs the memory pipe one request per lane and instruction
+// whatever its width, so the five entries Sigma(r, c5(i)) are three loads ({0, 1}, {2}, {3 + 2i, 4 + 2i}), not five.
+struct __attribute__((packed, aligned(8))) D2u { double x, y; };
+__device__ __forceinline__ void gather_row5(const double* __restrict__ row, int lm, double (&p)[5]) {
+    const D2u c01 = *reinterpret_cast<const D2u*>(row);
+    const D2u cl = *reinterpret_cast<const D2u*>(row + 3 + 2 * (size_t)lm);
+    p[0] = c01.x; p[1] = c01.y; p[2] = row[2]; p[3] = cl.x; p[4] = cl.y;
+}
 
 // the five non-zero columns of Hj for landmark lm: {0, 1, 2, 3+2lm, 4+2lm} (ekf_slam.cpp:164-170)
 __host__ __device__ __forceinline__ int idx5(int k, int lm) { return k < 3 ? k : 3 + 2 * lm + (k - 3); }

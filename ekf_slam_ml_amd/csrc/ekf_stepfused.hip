@@ -232,12 +232,9 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
             double k0 = 0.0, k1 = 0.0, g0 = 0.0, g1 = 0.0;
             if (r < Nb) {
                 double p[5], g[5];
+                gather_row5(Sg + (size_t)r * ld, lm, p);   // column gather (Sigma * H^T reads columns): three loads
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const int c = idx5(k, lm);
-                    p[k] = Sg[(size_t)r * ld + c];   // column gather (Sigma * H^T reads columns)
-                    g[k] = Sg[(size_t)c * ld + r];   // row gather    (H * Sigma reads rows)
-                }
+                for (int k = 0; k < 5; k++) g[k] = Sg[(size_t)idx5(k, lm) * ld + r];   // row gather (H * Sigma reads rows)
                 // ... as they stand now: minus the pending pairs, in order (four pairs' values requested together)
                 auto fold_rc = [&](int v, const double (&f)[4]) {
 #pragma unroll
