@@ -386,7 +386,9 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
                 for (int b = 0; b < B; b++) if (kc[b] > m) m = kc[b];
                 if (m < n) pvp.N = 3 + 2 * m;
             }
-            ekf::launch_predict(pvp, P.ulog_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream);
+            if (delayed) EKFC(P.ensure_callfused());
+            ekf::launch_predict(pvp, P.ulog_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream,
+                                delayed ? P.cf_pred : nullptr);
         }
         if (want_small && smax > 0 && Nstep <= ekf::small_max_dim()) {
             if (delayed) EKFC(timed_flush());   // (the LDS-resident step works on the materialised covariance)
@@ -402,12 +404,13 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
         if (smax > 0 && delayed) {
             // the step's pairs join the pending store (ekf_stepfused.hip, DELAYED): no pass over Sigma in this step
             EKFC(P.ensure_callfused());
+            EKFC(P.ensure_blk_cache());
             if (Nstep > 3 + 2 * kc_max) kc_max = (Nstep - 3) / 2;
             if (P.pend_count + 2 * jmax > P.pend_cap) EKFC(timed_flush());
             ekf::launch_pool_step_unknown_delayed(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
                                                   P.active_prefix ? 3 + 2 * P.touched_hwm : P.pv.N,
                                                   P.ulog_assoc + (size_t)t * B * jmax, P.pending(), P.corr_counter, P.cf_cnt,
-                                                  P.stream);
+                                                  P.blk_cache, P.cf_pred, P.stream);
             P.pend_count += 2 * jmax;
             P.form_counts[5]++;
             smax = 0;  // the step is done
@@ -416,6 +419,7 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
             // any prefix size: the whole step of every filter in ONE launch, its covariance streamed once per step
             // (ekf_stepfused.hip); bit-identical to the four launches per measurement slot below
             EKFC(P.ensure_callfused());
+            EKFC(P.ensure_blk_cache());
             if (Nstep > 3 + 2 * kc_max) kc_max = (Nstep - 3) / 2;
             // Big prefixes: the step kernel stops at the factor pairs and k_rank2v streams every covariance spread over
             // the whole chip (one workgroup per filter streams its 32 MB at 4.6 TB/s pool-wide, k_rank2v at 6.4).  Chosen
@@ -436,7 +440,8 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
                 pva.N = P.active_prefix ? Nstep : P.pv.N;
                 ekf::launch_pool_step_unknown(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
                                               P.active_prefix ? 3 + 2 * P.touched_hwm : P.pv.N, P.ulog_assoc + (size_t)t * B * jmax,
-                                              P.cf_U, P.cf_V, P.corr_counter, P.stream, P.cf_cnt, ekf::rank2v_round_count(smax));
+                                              P.cf_U, P.cf_V, P.corr_counter, P.stream, P.cf_cnt, ekf::rank2v_round_count(smax),
+                                              P.blk_cache);
                 if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
                 ekf::launch_rank2v(pva, P.cf_U, P.cf_V, P.cf_cnt, smax, P.tuning, P.stream);
                 P.form_counts[5]++;
@@ -444,7 +449,7 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
                 if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
                 ekf::launch_pool_step_unknown(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
                                               P.active_prefix ? 3 + 2 * P.touched_hwm : P.pv.N, P.ulog_assoc + (size_t)t * B * jmax,
-                                              P.cf_U, P.cf_V, P.corr_counter, P.stream);
+                                              P.cf_U, P.cf_V, P.corr_counter, P.stream, nullptr, 0, P.blk_cache);
             }
             if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
             k++;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_init(PoolView pv) {
 constexpr int kPredictThreads = 1024;
 
 __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const double* twist_dev, double dth_imm,
-                                                            double dx_imm, Pending pend) {
+                                                            double dx_imm, Pending pend, double* pred_out) {
     const int b = blockIdx.x;
     const int N = pv.N, ld = pv.ld;
     double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
         a20 = -(dx / dtheta) * sin_t + (dx / dtheta) * sin_td;
     }
     __syncthreads();  // all threads hold the old theta; thread 0 may now move the pose
+    if (pred_out && threadIdx.x == 0) { pred_out[(size_t)b * 2] = a10; pred_out[(size_t)b * 2 + 1] = a20; }
 
 #pragma unroll
     for (int q = 0; q < PRE; q++) {
@@ -840,8 +841,8 @@ void launch_init(const PoolView& pv, hipStream_t s) {
 }
 
 void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, double dx, const Pending& pend,
-                    hipStream_t s) {
-    hipLaunchKernelGGL(k_predict, dim3(pv.B), dim3(kPredictThreads), 0, s, pv, twist_dev, dtheta, dx, pend);
+                    hipStream_t s, double* pred_out) {
+    hipLaunchKernelGGL(k_predict, dim3(pv.B), dim3(kPredictThreads), 0, s, pv, twist_dev, dtheta, dx, pend, pred_out);
 }
 
 void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init, hipStream_t s) {

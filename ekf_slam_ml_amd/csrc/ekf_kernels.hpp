@@ -383,7 +383,7 @@ struct Rank2Tuning {
 void launch_init(const PoolView& pv, hipStream_t s);
 // prediction(): twist = imm (dtheta, dx) when twist_dev == nullptr, else twist_dev[b*2 + {0,1}]
 void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, double dx, const Pending& pend,
-                    hipStream_t s);
+                    hipStream_t s, double* pred_out = nullptr /* [B][2]: (a10, a20) of At, for the block cache */);
 // Delayed mode: one kernel per correction (no covariance stream); reads state from pv.state, writes the
 // corrected state to state_out (ping-pong) and appends the factor pair at rows pend.count, pend.count+1.
 void launch_gain_delayed(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
@@ -531,12 +531,13 @@ int rank2v_round_count(int vcount);   // corrections per pass, rounded up to an 
 // zero_upto = rank2v_round_count(jmax)): big prefixes stream faster spread over the chip than one workgroup per filter.
 void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                               int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s,
-                              int* cnt_out = nullptr, int zero_upto = 0);
+                              int* cnt_out, int zero_upto, double* blocks /* [B][25][n] scratch: the landmarks' current blocks */);
 // Delayed mode: the step's pairs (exactly jmax per filter, zero pairs beyond a filter's own readings) are appended to the
 // pool's pending store behind the pend.count / 2 pairs of earlier steps, which the step's readings see subtracted; nothing
 // is applied to Sigma (the caller flushes every few steps).  cnt_scratch: [B] ints.
 void launch_pool_step_unknown_delayed(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                                       int* assoc_out, const Pending& pend, unsigned long long* corr_counter, int* cnt_scratch,
+                                      double* blocks, const double* pred /* [B][2] (a10, a20) of the step's prediction */,
                                       hipStream_t s);
 int step_pending_pairs_max();   // pairs a filter can carry between flushes in that mode
 

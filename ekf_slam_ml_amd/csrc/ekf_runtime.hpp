@@ -213,6 +213,11 @@ struct Pool {
     double* cf_state = nullptr;    // [B][ld] out-of-place state of the factor kernel
     double* call_in = nullptr;     // single filter: [2n] sensor_reading | [1 + n] ints: V, visible landmarks
     double* cf_pred = nullptr;     // [B][2] (A10, A20) of a prediction folded into the call
+    double* blk_cache = nullptr;   // [B][25][n] pools' step-fused association: every landmark's current 5 x 5 block
+    ekf_status ensure_blk_cache() {
+        if (!blk_cache) EKFC(dalloc(&blk_cache, (size_t)pv.B * 25 * (pv.n > 0 ? pv.n : 1)));
+        return EKF_OK;
+    }
     bool call_fused_ok() const { return call_fused && pend_cap == 0 && !active_set && pv.n > 0 && pv.N > ekf::small_max_dim(); }
     ekf_status ensure_callfused() {
         if (!cf_U) {
@@ -483,7 +488,7 @@ struct Pool {
                         pv.touch_count, scores, meas_dev, assoc_block,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, sigma_alt, state_fz, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
-                        phase_trace, terms2, scores2, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred};
+                        phase_trace, terms2, scores2, blk_cache, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();

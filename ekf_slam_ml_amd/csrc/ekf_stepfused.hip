@@ -38,7 +38,8 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
                                                                     double* __restrict__ Vall,
                                                                     unsigned long long* __restrict__ corr_counter,
                                                                     int* __restrict__ cnt_out, int zero_upto, int p0,
-                                                                    int pair_rows) {
+                                                                    int pair_rows, double* __restrict__ blocks_all,
+                                                                    const double* __restrict__ pred) {
     constexpr int kPairs = DELAYED ? kStepPendingPairs : kCallV;
     // cnt_out == nullptr: the final pass runs here (one workgroup streams its filter's covariance).  Otherwise the step
     // ends with the pairs in Uall / Vall (rows beyond the filter's pair count zero-filled up to `zero_upto` pairs) and
@@ -46,17 +47,8 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
     const int b = blockIdx.x, tid = threadIdx.x;
     const int J = count ? count[b] : jmax;
     const int n = pv.n, ld = pv.ld;
-    if (J <= 0) {  // uniform
+    if (J <= 0 && !DELAYED) {  // uniform: nothing to do for this filter in this step
         if (cnt_out && tid == 0) cnt_out[b] = 0;
-        if constexpr (DELAYED) {   // the step's share of the pending store: zero pairs
-            double* Uz = Uall + (size_t)b * pair_rows * ld;
-            double* Vz = Vall + (size_t)b * pair_rows * ld;
-            for (int r = tid; r < ld; r += kStepThreads)
-                for (int v = p0; v < p0 + zero_upto; v++) {
-                    Uz[(size_t)(2 * v) * ld + r] = 0.0; Uz[(size_t)(2 * v + 1) * ld + r] = 0.0;
-                    Vz[(size_t)(2 * v) * ld + r] = 0.0; Vz[(size_t)(2 * v + 1) * ld + r] = 0.0;
-                }
-        }
         return;
     }
     // (no __restrict__: the pairs and the state are written and re-read by this workgroup, ordered by its barriers)
@@ -90,7 +82,67 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
             else sh_G5[v][q][h] = Vb[(size_t)(2 * v + h) * ld + q];
         }
     }
+    // ---- block cache (delayed mode): blk[e][i] = entry e of Sigma[c5(i), c5(i)] AS IT STANDS NOW (stored minus every pending
+    // pair), kept current by folding each new pair in.  A score then reads 25 consecutive-in-i values instead of 25 scattered
+    // entries of Sigma plus 8 values per pending pair (up to 64 pairs are pending).  (Re)built from Sigma when nothing is
+    // pending; carried across steps, where this step's prediction() is applied to it first (the 5 x 5 block is closed under At . At^T + Q: rows /
+    // columns 0, 1, 2 are inside it; k_predict's arithmetic).  Landmark i is always handled by thread i mod 512.
+    double* blk = DELAYED ? blocks_all + (size_t)b * 25 * n : nullptr;
+    if (!DELAYED) {
+    } else if (p0 == 0) {
+        for (int i = tid; i < n; i += kStepThreads) {
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+#pragma unroll
+                for (int l = 0; l < 5; l++) blk[(size_t)(5 * k + l) * n + i] = Sg[(size_t)idx5(k, i) * ld + idx5(l, i)];
+        }
+    } else {
+        const double a10 = pred[(size_t)b * 2], a20 = pred[(size_t)b * 2 + 1];
+        for (int i = tid; i < n; i += kStepThreads) {
+            double c[5][5];
+#pragma unroll
+            for (int e = 0; e < 25; e++) c[e / 5][e % 5] = blk[(size_t)e * n + i];
+            double o[5][5];
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+#pragma unroll
+                for (int l = 0; l < 5; l++) o[k][l] = c[k][l];
+#pragma unroll
+            for (int l = 3; l < 5; l++) {   // rows 1, 2 at the landmark's columns; columns 1, 2 at its rows
+                o[1][l] = a10 * c[0][l] + c[1][l];
+                o[2][l] = a20 * c[0][l] + c[2][l];
+                o[l][1] = c[l][0] * a10 + c[l][1];
+                o[l][2] = c[l][0] * a20 + c[l][2];
+            }
+            double T[3][3];
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+                T[0][l] = c[0][l];
+                T[1][l] = a10 * c[0][l] + c[1][l];
+                T[2][l] = a20 * c[0][l] + c[2][l];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                o[k][0] = T[k][0];
+                o[k][1] = T[k][0] * a10 + T[k][1];
+                o[k][2] = T[k][0] * a20 + T[k][2];
+            }
+            o[0][0] += pv.p.q_pose; o[1][1] += pv.p.q_pose; o[2][2] += pv.p.q_pose;   // Q = diag(q,q,q,0...) :40-43
+#pragma unroll
+            for (int e = 0; e < 25; e++) blk[(size_t)e * n + i] = o[e / 5][e % 5];
+        }
+    }
+    __threadfence_block();
     __syncthreads();
+    if (J <= 0) {   // (delayed mode, uniform) a filter that sits the step out: its cache is up to date, its pairs are zero pairs
+        if (cnt_out && tid == 0) cnt_out[b] = 0;
+        for (int r = tid; r < ld; r += kStepThreads)
+            for (int v = p0; v < p0 + zero_upto; v++) {
+                Ub[(size_t)(2 * v) * ld + r] = 0.0; Ub[(size_t)(2 * v + 1) * ld + r] = 0.0;
+                Vb[(size_t)(2 * v) * ld + r] = 0.0; Vb[(size_t)(2 * v + 1) * ld + r] = 0.0;
+            }
+        return;
+    }
 
     int pc = p0;  // pending pairs the next reading sees: earlier steps' (delayed mode) + this step's (uniform)
     for (int j = 0; j < J; j++) {  // :291 sequential, state-carrying
@@ -105,44 +157,49 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
             MeasTerms m;
             measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, theta, x, y, m);
             double S55[5][5], S[2][2], Si[2][2];
-            const int ia = 3 + 2 * i;
+            if constexpr (DELAYED) {
 #pragma unroll
-            for (int k = 0; k < 5; k++)
-#pragma unroll
-                for (int l = 0; l < 5; l++) S55[k][l] = Sg[(size_t)idx5(k, i) * ld + idx5(l, i)];
-            // the entries as they stand NOW: minus the pending pairs, in order (k_rank2's expression).  The pairs' values at
-            // the landmark's two indices come from memory: two pairs are requested together (in delayed mode up to 64
-            // pairs are pending, and one round trip per pair was most of the step)
-            auto fold_pair = [&](int v, const double (&ku)[2][2], const double (&gu)[2][2]) {
-                double kr[5][2], gc[5][2];
-#pragma unroll
-                for (int k = 0; k < 3; k++) { kr[k][0] = sh_K5[v][k][0]; kr[k][1] = sh_K5[v][k][1]; gc[k][0] = sh_G5[v][k][0]; gc[k][1] = sh_G5[v][k][1]; }
-#pragma unroll
-                for (int q = 0; q < 2; q++) { kr[3 + q][0] = ku[q][0]; kr[3 + q][1] = ku[q][1]; gc[3 + q][0] = gu[q][0]; gc[3 + q][1] = gu[q][1]; }
-#pragma unroll
+                for (int e = 0; e < 25; e++) S55[e / 5][e % 5] = blk[(size_t)e * n + i];   // current: every pending pair folded in
+            } else {
+                const int ia = 3 + 2 * i;
+    #pragma unroll
                 for (int k = 0; k < 5; k++)
-#pragma unroll
-                    for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
-            };
-            auto load_pair = [&](int v, double (&ku)[2][2], double (&gu)[2][2]) {
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    ku[q][0] = Ub[(size_t)(2 * v) * ld + ia + q]; ku[q][1] = Ub[(size_t)(2 * v + 1) * ld + ia + q];
-                    gu[q][0] = Vb[(size_t)(2 * v) * ld + ia + q]; gu[q][1] = Vb[(size_t)(2 * v + 1) * ld + ia + q];
+    #pragma unroll
+                    for (int l = 0; l < 5; l++) S55[k][l] = Sg[(size_t)idx5(k, i) * ld + idx5(l, i)];
+                // the entries as they stand NOW: minus the pending pairs, in order (k_rank2's expression).  The pairs' values at
+                // the landmark's two indices come from memory: two pairs are requested together (in delayed mode up to 64
+                // pairs are pending, and one round trip per pair was most of the step)
+                auto fold_pair = [&](int v, const double (&ku)[2][2], const double (&gu)[2][2]) {
+                    double kr[5][2], gc[5][2];
+    #pragma unroll
+                    for (int k = 0; k < 3; k++) { kr[k][0] = sh_K5[v][k][0]; kr[k][1] = sh_K5[v][k][1]; gc[k][0] = sh_G5[v][k][0]; gc[k][1] = sh_G5[v][k][1]; }
+    #pragma unroll
+                    for (int q = 0; q < 2; q++) { kr[3 + q][0] = ku[q][0]; kr[3 + q][1] = ku[q][1]; gc[3 + q][0] = gu[q][0]; gc[3 + q][1] = gu[q][1]; }
+    #pragma unroll
+                    for (int k = 0; k < 5; k++)
+    #pragma unroll
+                        for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
+                };
+                auto load_pair = [&](int v, double (&ku)[2][2], double (&gu)[2][2]) {
+    #pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        ku[q][0] = Ub[(size_t)(2 * v) * ld + ia + q]; ku[q][1] = Ub[(size_t)(2 * v + 1) * ld + ia + q];
+                        gu[q][0] = Vb[(size_t)(2 * v) * ld + ia + q]; gu[q][1] = Vb[(size_t)(2 * v + 1) * ld + ia + q];
+                    }
+                };
+                int v = 0;
+                for (; v + 2 <= pc; v += 2) {
+                    double ku[2][2][2], gu[2][2][2];
+    #pragma unroll
+                    for (int w = 0; w < 2; w++) load_pair(v + w, ku[w], gu[w]);
+    #pragma unroll
+                    for (int w = 0; w < 2; w++) fold_pair(v + w, ku[w], gu[w]);
                 }
-            };
-            int v = 0;
-            for (; v + 2 <= pc; v += 2) {
-                double ku[2][2][2], gu[2][2][2];
-#pragma unroll
-                for (int w = 0; w < 2; w++) load_pair(v + w, ku[w], gu[w]);
-#pragma unroll
-                for (int w = 0; w < 2; w++) fold_pair(v + w, ku[w], gu[w]);
-            }
-            for (; v < pc; v++) {
-                double ku[2][2], gu[2][2];
-                load_pair(v, ku, gu);
-                fold_pair(v, ku, gu);
+                for (; v < pc; v++) {
+                    double ku[2][2], gu[2][2];
+                    load_pair(v, ku, gu);
+                    fold_pair(v, ku, gu);
+                }
             }
             innovation_cov(S55, m.H, pv.p.r_meas, S);   // sums in the order of k_maha's shuffle folds
             inv2(S, Si);
@@ -205,12 +262,16 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
                 MeasTerms m;
                 measurement_terms(st[2 * lm + 3], st[2 * lm + 4], mx, my, theta, x, y, m);
                 double S55[5][5], S[2][2], Si[2][2];
-                for (int k = 0; k < 5; k++)
-                    for (int l = 0; l < 5; l++) {
-                        double xe = Sg[(size_t)idx5(k, lm) * ld + idx5(l, lm)];
-                        for (int v = 0; v < pc; v++) xe = xe - (sh_K5[v][k][0] * sh_G5[v][l][0] + sh_K5[v][k][1] * sh_G5[v][l][1]);
-                        S55[k][l] = xe;
-                    }
+                if constexpr (DELAYED) {
+                    for (int e = 0; e < 25; e++) S55[e / 5][e % 5] = blk[(size_t)e * n + lm];   // (current, see above)
+                } else {
+                    for (int k = 0; k < 5; k++)
+                        for (int l = 0; l < 5; l++) {
+                            double xe = Sg[(size_t)idx5(k, lm) * ld + idx5(l, lm)];
+                            for (int v = 0; v < pc; v++) xe = xe - (sh_K5[v][k][0] * sh_G5[v][l][0] + sh_K5[v][k][1] * sh_G5[v][l][1]);
+                            S55[k][l] = xe;
+                        }
+                }
                 innovation_cov(S55, m.H, pv.p.r_meas, S);
                 inv2(S, Si);
                 for (int k = 0; k < 5; k++) { sh_H[k] = m.H[0][k]; sh_H[5 + k] = m.H[1][k]; }
@@ -280,6 +341,28 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
             Vb[(size_t)(2 * pc) * ld + r] = g0;
             Vb[(size_t)(2 * pc + 1) * ld + r] = g1;
             if (r < 3) { sh_K5[pc][r][0] = k0; sh_K5[pc][r][1] = k1; sh_G5[pc][r][0] = g0; sh_G5[pc][r][1] = g1; }   // pose part of the new pair
+        }
+        __threadfence_block();
+        __syncthreads();
+        if constexpr (DELAYED) {   // the cached blocks take the new pair (k_rank2's expression); beyond the active dimension K = G = 0
+            const int nfold = min(n, (Nb - 3) >> 1);
+            for (int i = tid; i < nfold; i += kStepThreads) {
+                const int ia = 3 + 2 * i;
+                double kr[5][2], gc[5][2];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { kr[k][0] = sh_K5[pc][k][0]; kr[k][1] = sh_K5[pc][k][1]; gc[k][0] = sh_G5[pc][k][0]; gc[k][1] = sh_G5[pc][k][1]; }
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    kr[3 + q][0] = Ub[(size_t)(2 * pc) * ld + ia + q]; kr[3 + q][1] = Ub[(size_t)(2 * pc + 1) * ld + ia + q];
+                    gc[3 + q][0] = Vb[(size_t)(2 * pc) * ld + ia + q]; gc[3 + q][1] = Vb[(size_t)(2 * pc + 1) * ld + ia + q];
+                }
+#pragma unroll
+                for (int e = 0; e < 25; e++) {
+                    const int k = e / 5, l = e % 5;
+                    const double xv = blk[(size_t)e * n + i];
+                    blk[(size_t)e * n + i] = xv - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
+                }
+            }
         }
         pc++;
         __threadfence_block();
@@ -357,16 +440,16 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
 
 void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                               int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s,
-                              int* cnt_out, int zero_upto) {
+                              int* cnt_out, int zero_upto, double* blocks) {
     hipLaunchKernelGGL(k_pool_step_unknown<false>, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
-                       assoc_out, U, V, corr_counter, cnt_out, zero_upto, 0, 2 * kCallV);
+                       assoc_out, U, V, corr_counter, cnt_out, zero_upto, 0, 2 * kCallV, blocks, nullptr);
 }
 
 void launch_pool_step_unknown_delayed(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                                       int* assoc_out, const Pending& pend, unsigned long long* corr_counter, int* cnt_scratch,
-                                      hipStream_t s) {
+                                      double* blocks, const double* pred, hipStream_t s) {
     hipLaunchKernelGGL(k_pool_step_unknown<true>, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
-                       assoc_out, pend.U, pend.V, corr_counter, cnt_scratch, jmax, pend.count / 2, pend.cap);
+                       assoc_out, pend.U, pend.V, corr_counter, cnt_scratch, jmax, pend.count / 2, pend.cap, blocks, pred);
 }
 
 int step_pending_pairs_max() { return kStepPendingPairs; }
