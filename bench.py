@@ -585,10 +585,16 @@ def main():
         gwall, gcorr, _ = shard.reduce_throughput(t1 - t0, float(sg["corrections"]), float(sg["filter_steps"]), device=red_dev)
         if rank == 0:
             gstate = np.stack([bt.state(b) for b in range(nref)])
-            delayed["symmetric_gather"] = {"value": gcorr / gwall, "unit": "update steps/s",
-                                           "max_abs_state_diff_vs_eager": float(np.abs(gstate - rstate).max()),
-                                           "note": "opt-in: not the reference's operand (it reads the column); reported beside "
-                                                   "the default, never as `value` of this leg"}
+            gcov = bt.cov(0)
+            delayed["symmetric"] = {"value": gcorr / gwall, "unit": "update steps/s",
+                                    "flush_avg_ms": sg["rank2_ms"] / max(sg["rank2_launches"], 1),
+                                    "flush_form": "mirrored (k_flush_sym)" if bt.form_counts()["flush_mirrored"] else "full",
+                                    "max_abs_state_diff_vs_eager": float(np.abs(gstate - rstate).max()),
+                                    "max_rel_cov_diff_vs_eager": float(np.abs(gcov - rcov).max() / np.abs(rcov).max()),
+                                    "note": "opt-in (ekf_set_update_mode's symmetric option): Sigma H^T is taken as (H Sigma)^T "
+                                            "and the flush forms the tiles on and above the diagonal only, mirroring them -- "
+                                            "not the reference's operands (it reads the column and never symmetrises); "
+                                            "reported beside the default, never as `value` of this leg"}
         bt.set_update_mode(0)
 
     # Separately reported leg: the SAME steps with every measurement() call fused (ekf_callfused.hip) -- the gains and

@@ -531,11 +531,11 @@ class BatchEKF:
 
     def form_counts(self):
         """covariance passes per form since creation: plain / strip flushes, paired delayed gain launches, call-fused
-        passes, per-landmark rank-2 streams, step-fused launches with a separate pass"""
-        c = (C.c_longlong * 6)()
+        passes, per-landmark rank-2 streams, step-fused launches with a separate pass, mirrored flushes"""
+        c = (C.c_longlong * 8)()
         _check(self._lib.ekf_batch_form_counts(self._h, c))
-        return dict(zip(("flush_plain", "flush_strip", "gain_pairs", "call_fused_passes", "rank2_streams", "step_split_passes"),
-                        (int(x) for x in c)))
+        return dict(zip(("flush_plain", "flush_strip", "gain_pairs", "call_fused_passes", "rank2_streams", "step_split_passes",
+                         "flush_mirrored"), (int(x) for x in c)))
 
     def set_active_prefix(self, enable=True):
         self._form(FORM_ACTIVE_PREFIX, enable)

@@ -30,9 +30,9 @@ ekf_status ekf_batch_get_forms(ekf_batch_handle hb, unsigned* forms) {
     return EKF_OK;
 }
 
-ekf_status ekf_batch_form_counts(ekf_batch_handle hb, long long counts[6]) {
+ekf_status ekf_batch_form_counts(ekf_batch_handle hb, long long counts[8]) {
     if (!hb || !counts) return fail(EKF_ERR_INVALID, "null argument");
-    for (int i = 0; i < 6; i++) counts[i] = hb->pool.form_counts[i];
+    for (int i = 0; i < 8; i++) counts[i] = hb->pool.form_counts[i];
     return EKF_OK;
 }
 

@@ -22,6 +22,10 @@ constexpr int kMaxPending = 128;
 // grid (ceil(ld/512), B).  Reads: state (in), Sigma_base, U/V rows [0, count); writes: U/V rows
 // count, count+1, state_out, rec.  No buffer is both read and written -> race-free across workgroups.
 // ---------------------------------------------------------------------------------------------
+// SYM (ekf_set_update_mode's symmetric option): Sigma H^T is taken as (H Sigma)^T -- only the rows Sigma(c5, .) are
+// rebuilt, from coalesced base rows and the V half of the pending store; the column gathers and the U half of the factor
+// read (half of this kernel's traffic) are not made.
+template <bool SYM>
 __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, Pending pend,
                                                       double* __restrict__ state_out) {
     const int b = blockIdx.y;
@@ -134,10 +138,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
         for (int k = 0; k < 5; k++) {
             const int c = idx5(k, lm);
             g[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)c * ld + r);
-            if (pend.symmetric) {
-                p[k] = g[k];  // Sigma(r, c) taken as Sigma(c, r): coalesced instead of a 16-KB-strided gather
-                if (!two) p[k].y = 0.0;
-            } else {
+            if (!SYM) {
                 p[k].x = Sg[(size_t)r * ld + c];
                 p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
             }
@@ -145,8 +146,10 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
         // the factor rows of pairs j+2 and j+4 are in flight while pair j is folded in (trips past the end
         // re-read pair 0): this loop streams count x 32 B per lane and is bandwidth-bound
         auto ld4 = [&](int j, double2_t& a0, double2_t& a1, double2_t& b0, double2_t& b1) {
-            a0 = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
-            a1 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
+            if (!SYM) {
+                a0 = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
+                a1 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
+            }
             b0 = *reinterpret_cast<const double2_t*>(Vb + (size_t)j * ld + r);
             b1 = *reinterpret_cast<const double2_t*>(Vb + (size_t)(j + 1) * ld + r);
         };
@@ -159,13 +162,19 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
             for (int k = 0; k < 5; k++) {
                 const double v5a = sh_V5[k * kMaxPending + j], v5b = sh_V5[k * kMaxPending + j + 1];
                 const double u5a = sh_U5[k * kMaxPending + j], u5b = sh_U5[k * kMaxPending + j + 1];
-                p[k].x = __builtin_fma(-ub.x, v5b, __builtin_fma(-ua.x, v5a, p[k].x));
-                p[k].y = __builtin_fma(-ub.y, v5b, __builtin_fma(-ua.y, v5a, p[k].y));
+                if (!SYM) {
+                    p[k].x = __builtin_fma(-ub.x, v5b, __builtin_fma(-ua.x, v5a, p[k].x));
+                    p[k].y = __builtin_fma(-ub.y, v5b, __builtin_fma(-ua.y, v5a, p[k].y));
+                }
                 g[k].x = __builtin_fma(-u5b, vb.x, __builtin_fma(-u5a, va.x, g[k].x));
                 g[k].y = __builtin_fma(-u5b, vb.y, __builtin_fma(-u5a, va.y, g[k].y));
             }
             ua = ua1; ub = ub1; va = va1; vb = vb1;
             ua1 = ua2; ub1 = ub2; va1 = va2; vb1 = vb2;
+        }
+        if (SYM) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) { p[k] = g[k]; if (!two) p[k].y = 0.0; }
         }
         double2_t sht0 = zero2, sht1 = zero2;
 #pragma unroll
@@ -204,6 +213,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
 // (rows count .. count + 3; a filter whose second slot is empty appends a zero pair, one whose slots are both empty two).
 // Pose: the stale pose of the call (snap) for both corrections (ekf_slam.cpp:109-111).  grid (ceil(ld/512), B).
 // ---------------------------------------------------------------------------------------------
+template <bool SYM>
 __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc src, Pending pend,
                                                            double* __restrict__ state_out) {
     const int b = blockIdx.y;
@@ -258,12 +268,8 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
         for (int k = 0; k < 7; k++) {
             const int c = cidx(k);
             g[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)c * ld + r);
-            if (pend.symmetric) {
-                p[k] = g[k];
-                if (!two) p[k].y = 0.0;
-            }
         }
-        if (!pend.symmetric) {
+        if (!SYM) {
             // the seven column entries of a row as four loads: {0, 1}, {2}, and the two landmarks' neighbouring pairs
             const double* rw0 = Sg + (size_t)r * ld;
             const double* rw1 = Sg + (size_t)(two ? r + 1 : r) * ld;
@@ -363,8 +369,10 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     double2_t snew = zero2;
     if (row_live) {
         auto ld4 = [&](int j, double2_t& a0, double2_t& a1, double2_t& b0, double2_t& b1) {
-            a0 = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
-            a1 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
+            if (!SYM) {
+                a0 = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
+                a1 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
+            }
             b0 = *reinterpret_cast<const double2_t*>(Vb + (size_t)j * ld + r);
             b1 = *reinterpret_cast<const double2_t*>(Vb + (size_t)(j + 1) * ld + r);
         };
@@ -377,13 +385,19 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
             for (int k = 0; k < 7; k++) {
                 const double v5a = sh_V7[k * kMaxPending + j], v5b = sh_V7[k * kMaxPending + j + 1];
                 const double u5a = sh_U7[k * kMaxPending + j], u5b = sh_U7[k * kMaxPending + j + 1];
-                p[k].x = __builtin_fma(-ub.x, v5b, __builtin_fma(-ua.x, v5a, p[k].x));
-                p[k].y = __builtin_fma(-ub.y, v5b, __builtin_fma(-ua.y, v5a, p[k].y));
+                if (!SYM) {
+                    p[k].x = __builtin_fma(-ub.x, v5b, __builtin_fma(-ua.x, v5a, p[k].x));
+                    p[k].y = __builtin_fma(-ub.y, v5b, __builtin_fma(-ua.y, v5a, p[k].y));
+                }
                 g[k].x = __builtin_fma(-u5b, vb.x, __builtin_fma(-u5a, va.x, g[k].x));
                 g[k].y = __builtin_fma(-u5b, vb.y, __builtin_fma(-u5a, va.y, g[k].y));
             }
             ua = ua1; ub = ub1; va = va1; vb = vb1;
             ua1 = ua2; ub1 = ub2; va1 = va2; vb1 = vb2;
+        }
+        if (SYM) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) { p[k] = g[k]; if (!two) p[k].y = 0.0; }
         }
         // ---- correction 1: K1 = (Sigma H1^T) S1^-1, G1 = H1 Sigma on the lane's indices (:178) ----
         double2_t sht0 = zero2, sht1 = zero2;
@@ -710,14 +724,141 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Mirrored flush (the symmetric option of ekf_set_update_mode): Sigma_base -= sum_j U[j] V[j]^T is formed for the
+// tiles ON AND ABOVE the diagonal only and every tile above it is written twice, in place and mirrored -- 4 N^2 bytes
+// read + 8 N^2 written instead of 8 + 8, and half of the multiply-adds.  The elements on and above the diagonal carry
+// the same fused multiply-adds in the same order as k_flush's (bit-identical there); below it Sigma_base becomes their
+// mirror image, which is what the symmetric gain step (k_gain_delayed<true>) reads anyway.
+//   * Tile = 64 rows x 256 columns, one workgroup of 8 waves; wave w owns rows 8 w .. 8 w + 7, lane l the double2
+//     columns l and l + 64 (1-KB row segments per instruction, 8 rows x 4 columns per lane: k_flush_strip's register
+//     tile and its fl_batch).  Row tile ti's column groups start at its diagonal square: group g covers columns
+//     64 ti + 256 g ..; the square (the first 64 columns of group 0) is formed whole and written in place only.
+//   * U values are wave-uniform scalar operands (8 rows x 4 vectors per batch = 128 FMAs per lane), V comes through
+//     LDS in double-buffered chunks of 8 vectors (wave w stages vector w of a chunk).
+//   * The mirrored copy goes through LDS in four 64 x 64 transposes, so that a store instruction covers two 512-B
+//     row segments of the mirrored tile.
+// grid: B x (tiles per filter), XCD-aware decode as in k_flush.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSymRows = 64, kSymCols = 256, kSymChunk = 8, kSymLs = 66, kSymWaves = 8;
+constexpr int kSymMinDim = 256;     // below this the plain full flush is used (a handful of tiles per filter)
+
+__host__ __device__ inline int sym_groups(int ti, int ld) { return (ld - ti * kSymRows + kSymCols - 1) / kSymCols; }
+
+template <bool NT>
+__global__ __launch_bounds__(64 * kSymWaves) void k_flush_sym(double* __restrict__ sigma, const double* __restrict__ Uall,
+                                                              const double* __restrict__ Vall, int N, int ld,
+                                                              size_t sigma_stride, int cap, int count, int P, int B) {
+    __shared__ double sh[kSymRows * kSymLs];   // V chunks: 2 x 8 x 128 double2 = 32 KB; transposes: 64 x 66 doubles
+    int b, p;
+    const int full = (B / 8) * 8 * P;
+    if ((int)blockIdx.x < full) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b = (slot / P) * 8 + xcd;
+        p = slot % P;
+    } else {
+        const int rest = blockIdx.x - full;
+        b = (B / 8) * 8 + rest / P;
+        p = rest % P;
+    }
+    int ti = 0;
+    for (;; ti++) {
+        const int ng = sym_groups(ti, ld);
+        if (p < ng) break;
+        p -= ng;
+    }
+    const int g = p;
+    const int ld2n = ld >> 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = ti * kSymRows + 8 * wave;                       // the wave's first row
+    const int cfirst = ti * kSymRows + g * kSymCols;               // the tile's first column
+    const int c2 = (cfirst >> 1) + lane;                           // the lane's first double2 column (second: + 64)
+    const bool live0 = c2 < ld2n, live1 = c2 + 64 < ld2n;
+    const double* __restrict__ Ub = Uall + (size_t)b * cap * ld;
+    const double2_t* __restrict__ Vb = reinterpret_cast<const double2_t*>(Vall + (size_t)b * cap * ld) + c2;
+    double* __restrict__ Sg = sigma + (size_t)b * sigma_stride;
+    double2_t* __restrict__ col = reinterpret_cast<double2_t*>(Sg) + c2;
+    const double2_t zero2 = {0.0, 0.0};
+    const int rlast = N - 1;
+
+    double2_t a[8][2];
+    fl_load<NT>(a, col, r0, rlast, ld2n, live0, live1);   // (a wave whose rows all lie past the matrix re-reads the last row)
+
+    // V chunks through LDS: wave w stages vector w of a chunk
+    double2_t* shV = reinterpret_cast<double2_t*>(sh);   // [2][kSymChunk][128]
+    double2_t pv0, pv1;
+    auto v_fetch = [&](int j0) {
+        const int j = min(j0 + wave, count - 1);
+        pv0 = live0 ? Vb[(size_t)j * ld2n] : zero2;
+        pv1 = live1 ? Vb[(size_t)j * ld2n + 64] : zero2;
+    };
+    auto v_put = [&](int buf) {
+        shV[(buf * kSymChunk + wave) * 128 + lane] = pv0;
+        shV[(buf * kSymChunk + wave) * 128 + 64 + lane] = pv1;
+    };
+    v_fetch(0);
+    v_put(0);
+    __syncthreads();
+    const int rU = min(r0, ld - 8);   // (rows past the matrix: any finite operand, never stored)
+    int buf = 0;
+    for (int j0 = 0; j0 < count; j0 += kSymChunk) {
+        const bool more = j0 + kSymChunk < count;
+        if (more) v_fetch(j0 + kSymChunk);
+        const int nv = min(kSymChunk, count - j0);
+        const double2_t* __restrict__ sv = shV + buf * kSymChunk * 128 + lane;
+        int jj = 0;
+        for (; jj + 4 <= nv; jj += 4) fl_batch<4>(a, Ub + (size_t)(j0 + jj) * ld + rU, ld, sv + jj * kStripCols2);
+        if (jj < nv) fl_batch<2>(a, Ub + (size_t)(j0 + jj) * ld + rU, ld, sv + jj * kStripCols2);   // (count is even)
+        if (more) v_put(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // in place
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see k_flush_strip
+    if (r0 <= rlast) fl_store<NT>(a, col, r0, rlast, ld2n, live0, live1);
+    // mirrored: chunk q = the tile's columns 64 q .. 64 q + 63 (lanes 32 (q & 1) .., second column pair for q >= 2),
+    // transposed through LDS: sh[c][r], c = column inside the chunk, r = row inside the tile
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if ((q == 0 && g == 0) || cfirst + 64 * q >= N) continue;   // the diagonal square / a chunk outside the matrix (uniform)
+        if ((lane >> 5) == (q & 1)) {
+            const int cl = 2 * (lane & 31);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double2_t v = q < 2 ? a[u][0] : a[u][1];
+                sh[cl * kSymLs + 8 * wave + u] = v.x;
+                sh[(cl + 1) * kSymLs + 8 * wave + u] = v.y;
+            }
+        }
+        __syncthreads();
+        // target rows cfirst + 64 q + c, target columns 64 ti .. + 63: lanes 0..31 row c, lanes 32..63 row c + 1
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int c = 16 * it + 2 * wave + (lane >> 5);
+            const int tr = cfirst + 64 * q + c, tc = ti * kSymRows + 2 * (lane & 31);
+            if (tr < N && tc < N) {
+                const double2_t v = *reinterpret_cast<const double2_t*>(sh + c * kSymLs + 2 * (lane & 31));
+                double2_t* dst = reinterpret_cast<double2_t*>(Sg + (size_t)tr * ld + tc);
+                if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 void launch_gain_delayed(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
                          hipStream_t s) {
-    hipLaunchKernelGGL(k_gain_delayed, dim3((pv.ld / 2 + 255) / 256, pv.B), dim3(256), 0, s, pv, src, pend, state_out);
+    const dim3 grid((pv.ld / 2 + 255) / 256, pv.B);
+    if (pend.symmetric) hipLaunchKernelGGL(k_gain_delayed<true>, grid, dim3(256), 0, s, pv, src, pend, state_out);
+    else hipLaunchKernelGGL(k_gain_delayed<false>, grid, dim3(256), 0, s, pv, src, pend, state_out);
 }
 
 void launch_gain_delayed_pair(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
                               hipStream_t s) {
-    hipLaunchKernelGGL(k_gain_delayed_pair, dim3((pv.ld / 2 + 255) / 256, pv.B), dim3(256), 0, s, pv, src, pend, state_out);
+    const dim3 grid((pv.ld / 2 + 255) / 256, pv.B);
+    if (pend.symmetric) hipLaunchKernelGGL(k_gain_delayed_pair<true>, grid, dim3(256), 0, s, pv, src, pend, state_out);
+    else hipLaunchKernelGGL(k_gain_delayed_pair<false>, grid, dim3(256), 0, s, pv, src, pend, state_out);
 }
 
 // dynamic LDS beyond 64 KB has to be allowed per kernel and per device: once each, whichever host thread comes first
@@ -741,6 +882,16 @@ int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, 
     if (pend.count <= 0) return 0;
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
+    if (pend.symmetric && pv.N >= kSymMinDim && t.rows_per_block == 0) {
+        int P = 0;
+        for (int ti = 0; ti * kSymRows < pv.N; ti++) P += sym_groups(ti, pv.ld);
+        dim3 grid((unsigned)((long long)P * pv.B));
+        if (nt) hipLaunchKernelGGL((k_flush_sym<true>), grid, dim3(64 * kSymWaves), 0, s, pv.sigma, pend.U, pend.V, pv.N,
+                                   pv.ld, pv.sigma_stride, pend.cap, pend.count, P, pv.B);
+        else hipLaunchKernelGGL((k_flush_sym<false>), grid, dim3(64 * kSymWaves), 0, s, pv.sigma, pend.U, pend.V, pv.N,
+                                pv.ld, pv.sigma_stride, pend.cap, pend.count, P, pv.B);
+        return 6;
+    }
     // Strip form: the V strip in LDS (count x 2 KB, one workgroup of 16 waves per CU) and >= 2 workgroups per CU of
     // work.  Its time hardly depends on the count, the plain form's does (the stream floor up to 32 vectors, 1.4x at
     // 64: tools/flush_sweep.py) -- the strip form takes over beyond kStripFromCount vectors on pools that fill the chip.

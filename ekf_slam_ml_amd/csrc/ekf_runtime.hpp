@@ -267,7 +267,7 @@ struct Pool {
 
     // execution forms (ekf_set_forms): which launch structures may be taken where they apply
     unsigned forms = EKF_FORMS_DEFAULT;
-    long long form_counts[6] = {0, 0, 0, 0, 0, 0};   // ekf_batch_form_counts
+    long long form_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ekf_batch_form_counts
     long long* phase_trace = nullptr;                // [2][kTraceSlots], only while ekf_phase_trace is on
     ekf_status set_forms(unsigned f) {
         EKFC(use());  // (a prediction deferred under the old setting happens now)

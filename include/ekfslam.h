@@ -150,8 +150,9 @@ ekf_status ekf_batch_set_forms(ekf_batch_handle hb, unsigned forms);
 ekf_status ekf_batch_get_forms(ekf_batch_handle hb, unsigned* forms);
 /* Test hook: covariance passes of each form this pool has launched since it was created --
  * counts[0] plain flush, [1] strip-form flush, [2] paired delayed gain launches, [3] call-fused passes,
- * [4] per-landmark rank-2 streams, [5] step-fused launches with a separate pass. */
-ekf_status ekf_batch_form_counts(ekf_batch_handle hb, long long counts[6]);
+ * [4] per-landmark rank-2 streams, [5] step-fused launches with a separate pass, [6] mirrored flushes (symmetric
+ * option of ekf_set_update_mode), [7] reserved (0). */
+ekf_status ekf_batch_form_counts(ekf_batch_handle hb, long long counts[8]);
 
 /* Active-set covariance update (opt-in, default 0; reported separately from the dense contract path):
  * the eager correction streams only the rows of the TOUCHED set -- the pose rows and the rows of landmarks

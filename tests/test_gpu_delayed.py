@@ -203,6 +203,66 @@ def test_strip_form_flush_is_bit_identical_to_the_plain_flush(hip, B, n, k, vmax
     assert np.all(np.isfinite(res[0][1][0]))
 
 
+@pytest.mark.parametrize("B,n,k,vmax", [(3, 130, 6, 3), (9, 500, 16, 2), (4, 1000, 32, 2), (2, 333, 3, 1), (3, 300, 40, 2), (2, 200, 37, 1), (11, 160, 64, 2)])
+def test_mirrored_flush_of_the_symmetric_option(hip, oracle, B, n, k, vmax):
+    """k_flush_sym (symmetric option of set_update_mode, N >= 256): the tiles on and above the diagonal carry the plain
+    flush's multiply-adds in the same order -- bit-identical there after ONE flush from the same base -- and every tile
+    above the diagonal is written a second time, mirrored: below the diagonal squares the result is the exact mirror
+    image.  Ragged shapes: N not a multiple of 64 (partial last row tile), column groups that end inside the matrix,
+    pending counts that are not a multiple of 8 (partial last V chunk), pools that are not a multiple of 8 filters.
+    The whole run stays within 1e-9 of the CPU checker."""
+    T = k // vmax if vmax > 1 else k          # at most k corrections: the run's only flush is the one at its end
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=5000 + n, half_extent=4.0, min_spacing=0.15,
+                          max_visible_dis=1e9 if vmax == 1 else 2.0, vmax=vmax)
+    log = synth.make_known_log(cfg)
+    res = []
+    for rows in (0, 16):                      # rows_per_block != 0 pins the plain row-block flush
+        bt = hip.BatchEKF(B, n)
+        bt.set_update_mode(k, symmetric_gather=True)
+        bt.set_tuning(rows_per_block=rows)
+        bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+        st = bt.run_known(0, T, time_kernels=True)
+        fc = bt.form_counts()
+        assert st["rank2_launches"] == 1
+        assert (fc["flush_mirrored"], fc["flush_plain"] + fc["flush_strip"]) == ((1, 0) if rows == 0 else (0, 1))
+        res.append(([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)]))
+        bt.close()
+    N = 3 + 2 * n
+    tile = np.arange(N) // 64
+    above = tile[:, None] < tile[None, :]                     # strictly above the diagonal squares
+    on_or_above = tile[:, None] <= tile[None, :]
+    ref_s, ref_c, _ = oracle.batch_run_known(log, oracle.STRUCTURED, want_cov=True, fast=False)
+    for b in range(B):
+        m, p = res[0][1][b], res[1][1][b]
+        assert np.array_equal(res[0][0][b], res[1][0][b]), f"filter {b} state"
+        assert np.array_equal(m[on_or_above], p[on_or_above]), f"filter {b}: tiles on and above the diagonal"
+        assert np.array_equal(m.T[above], m[above]), f"filter {b}: mirror image"
+        assert np.all(np.isfinite(m))
+        assert_parity(res[0][0][b], m, ref_s[b], ref_c[b], FP64_TOL, f"filter {b} vs the checker")
+
+
+def test_symmetric_option_over_many_flushes(hip, oracle):
+    """The symmetric option end to end at n = 1000: paired gain steps that rebuild only the rows Sigma(c, .), mirrored
+    flushes every 8 steps, 40 steps: 1e-9 against the CPU checker, and the covariance handed back is symmetric to the
+    bit outside the 64 x 64 diagonal squares."""
+    B, n, T = 3, 1000, 40
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=321, half_extent=8.0, min_spacing=0.2, max_visible_dis=2.0, vmax=2)
+    log = synth.make_known_log(cfg)
+    bt = hip.BatchEKF(B, n)
+    bt.set_update_mode(16, symmetric_gather=True)
+    bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+    bt.run_known()
+    assert bt.form_counts()["flush_mirrored"] >= 5
+    ref_s, ref_c, _ = oracle.batch_run_known(log, oracle.STRUCTURED, want_cov=True, fast=False)
+    tile = np.arange(3 + 2 * n) // 64
+    above = tile[:, None] < tile[None, :]
+    for b in range(B):
+        c = bt.cov(b)
+        assert_parity(bt.state(b), c, ref_s[b], ref_c[b], FP64_TOL, f"filter {b}")
+        assert np.array_equal(c.T[above], c[above])
+    bt.close()
+
+
 @pytest.mark.parametrize("k,vmax", [(32, 2), (7, 5), (3, 4), (2, 3), (1, 2), (16, 1)])
 def test_paired_delayed_gain_steps(hip, oracle, k, vmax):
     """Delayed mode, two log slots per launch (k_gain_delayed_pair: the pending factor rows are read once for both
