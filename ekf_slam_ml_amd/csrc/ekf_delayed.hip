@@ -11,6 +11,7 @@
 // -ffp-contract=off), so the delayed path matches the eager path to rounding, not bit for bit.
 #include "ekf_kernels.hpp"
 
+#include <cstdlib>
 #include <mutex>
 
 namespace ekf {
@@ -730,26 +731,36 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
 // read + 8 N^2 written instead of 8 + 8, and half of the multiply-adds.  The elements on and above the diagonal carry
 // the same fused multiply-adds in the same order as k_flush's (bit-identical there); below it Sigma_base becomes their
 // mirror image, which is what the symmetric gain step (k_gain_delayed<true>) reads anyway.
-//   * Tile = 64 rows x 256 columns, one workgroup of 8 waves; wave w owns rows 8 w .. 8 w + 7, lane l the double2
-//     columns l and l + 64 (1-KB row segments per instruction, 8 rows x 4 columns per lane: k_flush_strip's register
-//     tile and its fl_batch).  Row tile ti's column groups start at its diagonal square: group g covers columns
-//     64 ti + 256 g ..; the square (the first 64 columns of group 0) is formed whole and written in place only.
+//   * Tile = 32 rows x 256 columns, one workgroup of 4 waves (four workgroups per CU: their load, multiply-add and
+//     store phases interleave; 64-row tiles with 8 waves were 11 % slower at 64 vectors); wave w owns rows 8 w ..
+//     8 w + 7, lane l the double2 columns l and l + 64 (1-KB row segments per instruction, 8 rows x 4 columns per lane:
+//     k_flush_strip's register tile and its fl_batch).  Row tile ti's column groups start at its diagonal square:
+//     group g covers columns 32 ti + 256 g ..; the square (the first 32 columns of group 0) is formed whole and
+//     written in place only.
 //   * U values are wave-uniform scalar operands (8 rows x 4 vectors per batch = 128 FMAs per lane), V comes through
-//     LDS in double-buffered chunks of 8 vectors (wave w stages vector w of a chunk).
-//   * The mirrored copy goes through LDS in four 64 x 64 transposes, so that a store instruction covers two 512-B
+//     LDS in double-buffered chunks of 8 vectors (wave w stages the vectors w and w + 4 of a chunk).
+//   * The mirrored copy goes through LDS in four 64-column transposes, so that a store instruction covers four 256-B
 //     row segments of the mirrored tile.
 // grid: B x (tiles per filter), XCD-aware decode as in k_flush.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSymRows = 64, kSymCols = 256, kSymChunk = 8, kSymLs = 66, kSymWaves = 8;
+constexpr int kSymCols = 256;
+constexpr int kSymWaves = 4;         // measured: 8 waves (64-row tiles) 41.0 ms, 4 waves 36.9 ms, 2 waves 40.7 ms at 64 vectors
 constexpr int kSymMinDim = 256;     // below this the plain full flush is used (a handful of tiles per filter)
 
-__host__ __device__ inline int sym_groups(int ti, int ld) { return (ld - ti * kSymRows + kSymCols - 1) / kSymCols; }
+__host__ __device__ inline int sym_groups(int ti, int ld, int tile_rows) {
+    return (ld - ti * tile_rows + kSymCols - 1) / kSymCols;
+}
 
-template <bool NT>
-__global__ __launch_bounds__(64 * kSymWaves) void k_flush_sym(double* __restrict__ sigma, const double* __restrict__ Uall,
-                                                              const double* __restrict__ Vall, int N, int ld,
-                                                              size_t sigma_stride, int cap, int count, int P, int B) {
-    __shared__ double sh[kSymRows * kSymLs];   // V chunks: 2 x 8 x 128 double2 = 32 KB; transposes: 64 x 66 doubles
+template <bool NT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_flush_sym(double* __restrict__ sigma, const double* __restrict__ Uall,
+                                                          const double* __restrict__ Vall, int N, int ld,
+                                                          size_t sigma_stride, int cap, int count, int P, int B) {
+    constexpr int TR = 8 * WAVES;          // tile rows
+    constexpr int LS = TR + 2;             // row pitch of the transposes (doubles; even: 16-B aligned read-back)
+    constexpr int CH = WAVES >= 4 ? 8 : 4; // vectors per V chunk
+    constexpr int VPW = CH / WAVES;        // vectors of a chunk a wave stages
+    constexpr int SH = 64 * LS > 2 * CH * 256 ? 64 * LS : 2 * CH * 256;
+    __shared__ double sh[SH];              // V chunks: 2 x CH x 128 double2; transposes: 64 x LS doubles
     int b, p;
     const int full = (B / 8) * 8 * P;
     if ((int)blockIdx.x < full) {
@@ -763,7 +774,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void k_flush_sym(double* __restrict
     }
     int ti = 0;
     for (;; ti++) {
-        const int ng = sym_groups(ti, ld);
+        const int ng = sym_groups(ti, ld, TR);
         if (p < ng) break;
         p -= ng;
     }
@@ -771,8 +782,8 @@ __global__ __launch_bounds__(64 * kSymWaves) void k_flush_sym(double* __restrict
     const int ld2n = ld >> 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r0 = ti * kSymRows + 8 * wave;                       // the wave's first row
-    const int cfirst = ti * kSymRows + g * kSymCols;               // the tile's first column
+    const int r0 = ti * TR + 8 * wave;                             // the wave's first row
+    const int cfirst = ti * TR + g * kSymCols;                     // the tile's first column
     const int c2 = (cfirst >> 1) + lane;                           // the lane's first double2 column (second: + 64)
     const bool live0 = c2 < ld2n, live1 = c2 + 64 < ld2n;
     const double* __restrict__ Ub = Uall + (size_t)b * cap * ld;
@@ -785,28 +796,34 @@ __global__ __launch_bounds__(64 * kSymWaves) void k_flush_sym(double* __restrict
     double2_t a[8][2];
     fl_load<NT>(a, col, r0, rlast, ld2n, live0, live1);   // (a wave whose rows all lie past the matrix re-reads the last row)
 
-    // V chunks through LDS: wave w stages vector w of a chunk
-    double2_t* shV = reinterpret_cast<double2_t*>(sh);   // [2][kSymChunk][128]
-    double2_t pv0, pv1;
+    // V chunks through LDS: wave w stages the vectors w, w + WAVES, .. of a chunk
+    double2_t* shV = reinterpret_cast<double2_t*>(sh);   // [2][CH][128]
+    double2_t pv[VPW][2];
     auto v_fetch = [&](int j0) {
-        const int j = min(j0 + wave, count - 1);
-        pv0 = live0 ? Vb[(size_t)j * ld2n] : zero2;
-        pv1 = live1 ? Vb[(size_t)j * ld2n + 64] : zero2;
+#pragma unroll
+        for (int q = 0; q < VPW; q++) {
+            const int j = min(j0 + wave + WAVES * q, count - 1);
+            pv[q][0] = live0 ? Vb[(size_t)j * ld2n] : zero2;
+            pv[q][1] = live1 ? Vb[(size_t)j * ld2n + 64] : zero2;
+        }
     };
     auto v_put = [&](int buf) {
-        shV[(buf * kSymChunk + wave) * 128 + lane] = pv0;
-        shV[(buf * kSymChunk + wave) * 128 + 64 + lane] = pv1;
+#pragma unroll
+        for (int q = 0; q < VPW; q++) {
+            shV[(buf * CH + wave + WAVES * q) * 128 + lane] = pv[q][0];
+            shV[(buf * CH + wave + WAVES * q) * 128 + 64 + lane] = pv[q][1];
+        }
     };
     v_fetch(0);
     v_put(0);
     __syncthreads();
     const int rU = min(r0, ld - 8);   // (rows past the matrix: any finite operand, never stored)
     int buf = 0;
-    for (int j0 = 0; j0 < count; j0 += kSymChunk) {
-        const bool more = j0 + kSymChunk < count;
-        if (more) v_fetch(j0 + kSymChunk);
-        const int nv = min(kSymChunk, count - j0);
-        const double2_t* __restrict__ sv = shV + buf * kSymChunk * 128 + lane;
+    for (int j0 = 0; j0 < count; j0 += CH) {
+        const bool more = j0 + CH < count;
+        if (more) v_fetch(j0 + CH);
+        const int nv = min(CH, count - j0);
+        const double2_t* __restrict__ sv = shV + buf * CH * 128 + lane;
         int jj = 0;
         for (; jj + 4 <= nv; jj += 4) fl_batch<4>(a, Ub + (size_t)(j0 + jj) * ld + rU, ld, sv + jj * kStripCols2);
         if (jj < nv) fl_batch<2>(a, Ub + (size_t)(j0 + jj) * ld + rU, ld, sv + jj * kStripCols2);   // (count is even)
@@ -819,26 +836,29 @@ __global__ __launch_bounds__(64 * kSymWaves) void k_flush_sym(double* __restrict
     if (r0 <= rlast) fl_store<NT>(a, col, r0, rlast, ld2n, live0, live1);
     // mirrored: chunk q = the tile's columns 64 q .. 64 q + 63 (lanes 32 (q & 1) .., second column pair for q >= 2),
     // transposed through LDS: sh[c][r], c = column inside the chunk, r = row inside the tile
+    constexpr int LPR = TR / 2;            // lanes per mirrored row segment (TR doubles)
+    constexpr int RPI = 64 / LPR;          // mirrored rows per store instruction
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        if ((q == 0 && g == 0) || cfirst + 64 * q >= N) continue;   // the diagonal square / a chunk outside the matrix (uniform)
+        // the diagonal square (the first TR columns of group 0) is written in place only; chunks outside the matrix: nothing
+        if ((g == 0 && 64 * (q + 1) <= TR) || cfirst + 64 * q >= N) continue;   // (uniform)
         if ((lane >> 5) == (q & 1)) {
             const int cl = 2 * (lane & 31);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const double2_t v = q < 2 ? a[u][0] : a[u][1];
-                sh[cl * kSymLs + 8 * wave + u] = v.x;
-                sh[(cl + 1) * kSymLs + 8 * wave + u] = v.y;
+                sh[cl * LS + 8 * wave + u] = v.x;
+                sh[(cl + 1) * LS + 8 * wave + u] = v.y;
             }
         }
         __syncthreads();
-        // target rows cfirst + 64 q + c, target columns 64 ti .. + 63: lanes 0..31 row c, lanes 32..63 row c + 1
+        // mirrored rows cfirst + 64 q + c, columns TR ti .. + TR - 1: LPR lanes per row, RPI rows per instruction
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int c = 16 * it + 2 * wave + (lane >> 5);
-            const int tr = cfirst + 64 * q + c, tc = ti * kSymRows + 2 * (lane & 31);
-            if (tr < N && tc < N) {
-                const double2_t v = *reinterpret_cast<const double2_t*>(sh + c * kSymLs + 2 * (lane & 31));
+        for (int it = 0; it < 64 / (WAVES * RPI); it++) {
+            const int c = WAVES * RPI * it + RPI * wave + lane / LPR;
+            const int tr = cfirst + 64 * q + c, tc = ti * TR + 2 * (lane % LPR);
+            if (tr < N && tc < N && !(g == 0 && 64 * q + c < TR)) {
+                const double2_t v = *reinterpret_cast<const double2_t*>(sh + c * LS + 2 * (lane % LPR));
                 double2_t* dst = reinterpret_cast<double2_t*>(Sg + (size_t)tr * ld + tc);
                 if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
             }
@@ -883,13 +903,14 @@ int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, 
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
     if (pend.symmetric && pv.N >= kSymMinDim && t.rows_per_block == 0) {
+        constexpr int tr = 8 * kSymWaves;
         int P = 0;
-        for (int ti = 0; ti * kSymRows < pv.N; ti++) P += sym_groups(ti, pv.ld);
+        for (int ti = 0; ti * tr < pv.N; ti++) P += sym_groups(ti, pv.ld, tr);
         dim3 grid((unsigned)((long long)P * pv.B));
-        if (nt) hipLaunchKernelGGL((k_flush_sym<true>), grid, dim3(64 * kSymWaves), 0, s, pv.sigma, pend.U, pend.V, pv.N,
-                                   pv.ld, pv.sigma_stride, pend.cap, pend.count, P, pv.B);
-        else hipLaunchKernelGGL((k_flush_sym<false>), grid, dim3(64 * kSymWaves), 0, s, pv.sigma, pend.U, pend.V, pv.N,
-                                pv.ld, pv.sigma_stride, pend.cap, pend.count, P, pv.B);
+#define EKF_FS_ARGS pv.sigma, pend.U, pend.V, pv.N, pv.ld, pv.sigma_stride, pend.cap, pend.count, P, pv.B
+        if (nt) hipLaunchKernelGGL((k_flush_sym<true, kSymWaves>), grid, dim3(64 * kSymWaves), 0, s, EKF_FS_ARGS);
+        else hipLaunchKernelGGL((k_flush_sym<false, kSymWaves>), grid, dim3(64 * kSymWaves), 0, s, EKF_FS_ARGS);
+#undef EKF_FS_ARGS
         return 6;
     }
     // Strip form: the V strip in LDS (count x 2 KB, one workgroup of 16 waves per CU) and >= 2 workgroups per CU of

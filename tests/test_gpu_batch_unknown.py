@@ -458,3 +458,34 @@ def test_delayed_data_association_for_pools(hip, oracle, k, surveyed_share):
     o, known, d = _oracle_replay(oracle, lg, b, n, 0, T, o, known)
     assert np.array_equal(snap[1][0][:, b], d), "decisions differ from the checker"
     assert_parity(snap[1][2][b], snap[1][3][0], o.state, o.cov, FP64_TOL, "delayed pool association vs dense checker")
+
+
+def test_delayed_data_association_with_the_symmetric_option(hip):
+    """Pools' delayed data_association() with the symmetric option: the step kernel keeps reading columns and rows of the
+    stored covariance, which the mirrored flush (k_flush_sym) leaves exactly symmetric outside its diagonal squares --
+    decisions and known counts identical to the eager run, states and covariances within 1e-9."""
+    n, B, T = 170, 9, 10
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=777, half_extent=5.0, min_spacing=0.3, max_visible_dis=1.4, vmax=8,
+                          v_cmd=1.0, w_cmd=0.6)
+    log = synth.make_unknown_log(cfg)
+    rng = np.random.default_rng(6)
+    init = (log.world[None] + rng.normal(0.0, 0.005, size=(B, n, 2))).reshape(B, 2 * n)
+    lm0 = np.full((2, B, 1), -1, dtype=np.int32)
+    snap = []
+    for mode in (0, 24):
+        bt = hip.BatchEKF(B, n)
+        bt.upload_known_log(np.zeros((2, B, 2)), lm0, np.zeros((2, B, 1, 2)), init)
+        bt.run_known()
+        bt.set_known_counts(np.full(B, n, dtype=np.int32))
+        bt.set_update_mode(mode, symmetric_gather=bool(mode))
+        bt.upload_unknown_log(log.twist, log.count, log.meas_xy)
+        bt.run_unknown(0, T)
+        if mode:
+            assert bt.form_counts()["flush_mirrored"] >= 3
+        snap.append((bt.decisions().copy(), bt.known_counts().copy(), [bt.state(b) for b in range(B)], bt.cov(B - 1)))
+        bt.close()
+    assert np.array_equal(snap[0][0], snap[1][0]) and np.array_equal(snap[0][1], snap[1][1])
+    for b in range(B):
+        assert np.abs(snap[0][2][b] - snap[1][2][b]).max() < 1e-9
+    assert_parity(snap[1][2][B - 1], snap[1][3], snap[0][2][B - 1], snap[0][3], FP64_TOL, "symmetric delayed vs eager")
+

@@ -208,7 +208,7 @@ def test_mirrored_flush_of_the_symmetric_option(hip, oracle, B, n, k, vmax):
     """k_flush_sym (symmetric option of set_update_mode, N >= 256): the tiles on and above the diagonal carry the plain
     flush's multiply-adds in the same order -- bit-identical there after ONE flush from the same base -- and every tile
     above the diagonal is written a second time, mirrored: below the diagonal squares the result is the exact mirror
-    image.  Ragged shapes: N not a multiple of 64 (partial last row tile), column groups that end inside the matrix,
+    image.  Ragged shapes: N not a multiple of 32 (partial last row tile), column groups that end inside the matrix,
     pending counts that are not a multiple of 8 (partial last V chunk), pools that are not a multiple of 8 filters.
     The whole run stays within 1e-9 of the CPU checker."""
     T = k // vmax if vmax > 1 else k          # at most k corrections: the run's only flush is the one at its end
@@ -228,8 +228,8 @@ def test_mirrored_flush_of_the_symmetric_option(hip, oracle, B, n, k, vmax):
         res.append(([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)]))
         bt.close()
     N = 3 + 2 * n
-    tile = np.arange(N) // 64
-    above = tile[:, None] < tile[None, :]                     # strictly above the diagonal squares
+    tile = np.arange(N) // 32
+    above = tile[:, None] < tile[None, :]                     # strictly above the diagonal squares (32 x 32)
     on_or_above = tile[:, None] <= tile[None, :]
     ref_s, ref_c, _ = oracle.batch_run_known(log, oracle.STRUCTURED, want_cov=True, fast=False)
     for b in range(B):
@@ -244,7 +244,7 @@ def test_mirrored_flush_of_the_symmetric_option(hip, oracle, B, n, k, vmax):
 def test_symmetric_option_over_many_flushes(hip, oracle):
     """The symmetric option end to end at n = 1000: paired gain steps that rebuild only the rows Sigma(c, .), mirrored
     flushes every 8 steps, 40 steps: 1e-9 against the CPU checker, and the covariance handed back is symmetric to the
-    bit outside the 64 x 64 diagonal squares."""
+    bit outside the 32 x 32 diagonal squares."""
     B, n, T = 3, 1000, 40
     cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=321, half_extent=8.0, min_spacing=0.2, max_visible_dis=2.0, vmax=2)
     log = synth.make_known_log(cfg)
@@ -254,7 +254,7 @@ def test_symmetric_option_over_many_flushes(hip, oracle):
     bt.run_known()
     assert bt.form_counts()["flush_mirrored"] >= 5
     ref_s, ref_c, _ = oracle.batch_run_known(log, oracle.STRUCTURED, want_cov=True, fast=False)
-    tile = np.arange(3 + 2 * n) // 64
+    tile = np.arange(3 + 2 * n) // 32
     above = tile[:, None] < tile[None, :]
     for b in range(B):
         c = bt.cov(b)
