@@ -157,12 +157,14 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
     }
     HIPC(hipEventRecord(P.ev_begin, P.stream));
     size_t k = 0;
+    bool cols_stale = false;   // (see upper_run below)
     auto timed_flush = [&]() -> ekf_status {
         if (P.pend_count == 0) return EKF_OK;
         if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
         EKFC(P.flush());
         if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
         k++;
+        cols_stale = false;    // (a mirroring flush rewrites everything below the diagonal squares)
         return EKF_OK;
     };
     ekf::CmdSrc src{};
@@ -186,8 +188,13 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
             if (cand > P.touched_bound) P.touched_bound = cand;
         }
     }
+    // symmetric option with mirroring flushes: between flushes the tiles on and above the diagonal are the covariance
+    // (Pending::symmetric == 2: the prediction leaves the strided column entries below the first square alone)
+    const bool upper_run = delayed && ekf::sym_flush_applies(P.pv, P.pending(), P.tuning);
     for (int t = small_run ? t_end : t_begin; t < t_end; t++) {
-        ekf::launch_predict(P.pv, P.log_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream);  // prediction()
+        ekf::Pending pdp = P.pending();
+        if (upper_run) { pdp.symmetric = 2; cols_stale = true; }
+        ekf::launch_predict(P.pv, P.log_twist + (size_t)t * B * 2, 0.0, 0.0, pdp, P.stream);  // prediction()
         ekf::launch_measure_begin(P.pv, P.log_init, !P.init_flag, P.stream);               // measurement() top
         P.init_flag = 1;
         src.lm_idx = P.log_lm + (size_t)t * B * vmax;
@@ -239,6 +246,7 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
         }
     }
     if (delayed) EKFC(timed_flush());  // every run leaves Sigma materialised
+    if (cols_stale) ekf::launch_sym_repair(P.pv, P.stream);   // (predictions after the last flush)
     const size_t passes = k;
     HIPC(hipEventRecord(P.ev_end, P.stream));
     EKFC(checked_launch());

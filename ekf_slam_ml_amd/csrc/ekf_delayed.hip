@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
     __syncthreads();
     if (tid < 25) {
         const int k = tid / 5, l = tid % 5;
-        double v = Sg[(size_t)idx5(k, lm) * ld + idx5(l, lm)];
+        double v = SYM ? Sg[(size_t)min(idx5(k, lm), idx5(l, lm)) * ld + max(idx5(k, lm), idx5(l, lm))]   // (upper triangle)
+                       : Sg[(size_t)idx5(k, lm) * ld + idx5(l, lm)];
         for (int j = 0; j < rc; j += 2)
             v = __builtin_fma(-sh_U5[k * kMaxPending + j + 1], sh_V5[l * kMaxPending + j + 1],
                               __builtin_fma(-sh_U5[k * kMaxPending + j], sh_V5[l * kMaxPending + j], v));
@@ -142,6 +143,9 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
             if (!SYM) {
                 p[k].x = Sg[(size_t)r * ld + c];
                 p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
+            } else if (r < 4 && k >= 3) {   // Sigma(c, 1), Sigma(c, 2) from the rows 1, 2 (see Pending::symmetric == 2)
+                if (r == 0) g[k].y = Sg[(size_t)1 * ld + c];
+                else g[k].x = Sg[(size_t)2 * ld + c];
             }
         }
         // the factor rows of pairs j+2 and j+4 are in flight while pair j is folded in (trips past the end
@@ -269,6 +273,10 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
         for (int k = 0; k < 7; k++) {
             const int c = cidx(k);
             g[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)c * ld + r);
+            if (SYM && r < 4 && k >= 3) {   // Sigma(c, 1), Sigma(c, 2) from the rows 1, 2 (see Pending::symmetric == 2)
+                if (r == 0) g[k].y = Sg[(size_t)1 * ld + c];
+                else g[k].x = Sg[(size_t)2 * ld + c];
+            }
         }
         if (!SYM) {
             // the seven column entries of a row as four loads: {0, 1}, {2}, and the two landmarks' neighbouring pairs
@@ -294,7 +302,8 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     __syncthreads();
     if (tid < 49) {
         const int k = tid / 7, l = tid % 7;
-        double v = Sg[(size_t)cidx(k) * ld + cidx(l)];
+        double v = SYM ? Sg[(size_t)min(cidx(k), cidx(l)) * ld + max(cidx(k), cidx(l))]   // (upper triangle)
+                       : Sg[(size_t)cidx(k) * ld + cidx(l)];
         for (int j = 0; j < rc; j += 2)
             v = __builtin_fma(-sh_U7[k * kMaxPending + j + 1], sh_V7[l * kMaxPending + j + 1],
                               __builtin_fma(-sh_U7[k * kMaxPending + j], sh_V7[l * kMaxPending + j], v));
@@ -744,7 +753,8 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
 // grid: B x (tiles per filter), XCD-aware decode as in k_flush.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSymCols = 256;
-constexpr int kSymWaves = 4;         // measured: 8 waves (64-row tiles) 41.0 ms, 4 waves 36.9 ms, 2 waves 40.7 ms at 64 vectors
+static_assert(kSymSquare == 32, "k_predict keeps columns 1, 2 up inside the first diagonal square");
+constexpr int kSymWaves = kSymSquare / 8;         // measured: 8 waves (64-row tiles) 41.0 ms, 4 waves 36.9 ms, 2 waves 40.7 ms at 64 vectors
 constexpr int kSymMinDim = 256;     // below this the plain full flush is used (a handful of tiles per filter)
 
 __host__ __device__ inline int sym_groups(int ti, int ld, int tile_rows) {
@@ -898,11 +908,31 @@ static bool strip_flush_allowed() {
     return ok[dev];
 }
 
+// Columns 1 and 2 below the first diagonal square from the rows 1 and 2: ends a run whose last predictions (symmetric
+// == 2: rows only) were not followed by a mirrored flush.  grid (ceil(N / 256), B).
+__global__ __launch_bounds__(256) void k_sym_repair(double* __restrict__ sigma, int N, int ld, size_t sigma_stride) {
+    const int k = kSymSquare + blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    double* Sg = sigma + (size_t)blockIdx.y * sigma_stride;
+    Sg[(size_t)k * ld + 1] = Sg[(size_t)1 * ld + k];
+    Sg[(size_t)k * ld + 2] = Sg[(size_t)2 * ld + k];
+}
+
+void launch_sym_repair(const PoolView& pv, hipStream_t s) {
+    if (pv.N <= kSymSquare) return;
+    hipLaunchKernelGGL(k_sym_repair, dim3((pv.N - kSymSquare + 255) / 256, pv.B), dim3(256), 0, s, pv.sigma, pv.N, pv.ld,
+                       pv.sigma_stride);
+}
+
+bool sym_flush_applies(const PoolView& pv, const Pending& pend, const Rank2Tuning& t) {
+    return pend.symmetric && pv.N >= kSymMinDim && t.rows_per_block == 0;
+}
+
 int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s) {
     if (pend.count <= 0) return 0;
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
-    if (pend.symmetric && pv.N >= kSymMinDim && t.rows_per_block == 0) {
+    if (sym_flush_applies(pv, pend, t)) {
         constexpr int tr = 8 * kSymWaves;
         int P = 0;
         for (int ti = 0; ti * tr < pv.N; ti++) P += sym_groups(ti, pv.ld, tr);

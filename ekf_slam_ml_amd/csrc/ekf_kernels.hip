@@ -72,6 +72,10 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
     // trigonometry and fly under it.
     constexpr int PRE = 2;
     double s0[PRE], s1[PRE], s2[PRE], r0[PRE], r1[PRE], r2[PRE];
+    // pend.symmetric == 2 (a delayed known-association run with the mirrored flush): the tiles on and above the diagonal
+    // are the covariance until the next flush mirrors them, so columns 1 and 2 are only kept up inside the first
+    // diagonal square -- the 16-KB-strided sector per row (most of this kernel's traffic) is not touched
+    const int col_rows = pend.symmetric == 2 ? kSymSquare : N;
     // active-set mode: row/column k of a never-corrected landmark is exactly zero against the pose block,
     // so its update a*0 + 0 = 0 is skipped (bit-identical)
     const unsigned char* tf = pv.touch_flag + (size_t)b * pv.n;
@@ -84,8 +88,10 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
             s0[q] = Sg[k];                      // row 0 (coalesced)
             s1[q] = Sg[(size_t)1 * ld + k];
             s2[q] = Sg[(size_t)2 * ld + k];
-            const double* rowk = Sg + (size_t)k * ld;  // columns 0..2 of row k (one 32-B sector)
-            r0[q] = rowk[0]; r1[q] = rowk[1]; r2[q] = rowk[2];
+            if (k < col_rows) {
+                const double* rowk = Sg + (size_t)k * ld;  // columns 0..2 of row k (one 32-B sector)
+                r0[q] = rowk[0]; r1[q] = rowk[1]; r2[q] = rowk[2];
+            }
         }
     }
     double c[3][3], px = 0.0, py = 0.0;
@@ -125,8 +131,10 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
             double* rowk = Sg + (size_t)k * ld;
             Sg[(size_t)1 * ld + k] = a10 * s0[q] + s1[q];
             Sg[(size_t)2 * ld + k] = a20 * s0[q] + s2[q];
-            rowk[1] = r0[q] * a10 + r1[q];
-            rowk[2] = r0[q] * a20 + r2[q];
+            if (k < col_rows) {
+                rowk[1] = r0[q] * a10 + r1[q];
+                rowk[2] = r0[q] * a20 + r2[q];
+            }
         }
     }
     for (int k = 3 + threadIdx.x + PRE * kPredictThreads; k < N; k += kPredictThreads) {
@@ -134,12 +142,14 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
         const double t0 = Sg[k];
         const double t1 = Sg[(size_t)1 * ld + k];
         const double t2 = Sg[(size_t)2 * ld + k];
-        double* rowk = Sg + (size_t)k * ld;
-        const double q0 = rowk[0], q1 = rowk[1], q2 = rowk[2];
         Sg[(size_t)1 * ld + k] = a10 * t0 + t1;
         Sg[(size_t)2 * ld + k] = a20 * t0 + t2;
-        rowk[1] = q0 * a10 + q1;
-        rowk[2] = q0 * a20 + q2;
+        if (k < col_rows) {
+            double* rowk = Sg + (size_t)k * ld;
+            const double q0 = rowk[0], q1 = rowk[1], q2 = rowk[2];
+            rowk[1] = q0 * a10 + q1;
+            rowk[2] = q0 * a20 + q2;
+        }
     }
     // Delayed-update mode: Sigma = Sigma_base - sum_j u_j v_j^T with pending factors; At (.) At^T maps the
     // base (above) and every factor: u <- At u, v <- At v (only entries 1 and 2 change).

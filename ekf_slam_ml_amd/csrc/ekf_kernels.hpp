@@ -46,8 +46,11 @@ struct Pending {
     double* V;
     int cap;
     int count;
-    int symmetric;  // 1: the gain step reads Sigma_base(c5, r) for Sigma_base(r, c5) (see ekf_set_update_mode)
+    int symmetric;  // 1: the gain step takes Sigma H^T as (H Sigma)^T (see ekf_set_update_mode); 2: and, inside a delayed
+                    // known-association run whose flushes mirror (sym_flush_applies), the tiles on and above the diagonal
+                    // ARE the covariance between flushes: k_predict leaves columns 1, 2 below the first square alone
 };
+constexpr int kSymSquare = 32;   // side of the mirrored flush's diagonal squares (its tile rows)
 
 struct Params {
     double sigma0_landmark, q_pose, r_meas, gate_new, gate_update, straight_eps;
@@ -395,6 +398,8 @@ void launch_gain_delayed_pair(const PoolView& pv, const CmdSrc& src, const Pendi
 // Sigma_base -= sum_j U[j] V[j]^T for j < pend.count (count even); the caller then resets count to 0.
 // Returns the form taken: 0 plain (k_flush), 1 strip (k_flush_strip).
 int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s);
+bool sym_flush_applies(const PoolView& pv, const Pending& pend, const Rank2Tuning& t);   // launch_flush would mirror
+void launch_sym_repair(const PoolView& pv, hipStream_t s);
 // top of measurement(): pose snapshot (+ first-call landmark initialisation from init_xy [B][2n])
 void launch_measure_begin(const PoolView& pv, const double* init_xy, int do_init, hipStream_t s);
 void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s);

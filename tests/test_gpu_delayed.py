@@ -241,18 +241,27 @@ def test_mirrored_flush_of_the_symmetric_option(hip, oracle, B, n, k, vmax):
         assert_parity(res[0][0][b], m, ref_s[b], ref_c[b], FP64_TOL, f"filter {b} vs the checker")
 
 
-def test_symmetric_option_over_many_flushes(hip, oracle):
-    """The symmetric option end to end at n = 1000: paired gain steps that rebuild only the rows Sigma(c, .), mirrored
-    flushes every 8 steps, 40 steps: 1e-9 against the CPU checker, and the covariance handed back is symmetric to the
-    bit outside the 32 x 32 diagonal squares."""
+@pytest.mark.parametrize("blind_tail", [0, 3])
+def test_symmetric_option_over_many_flushes(hip, oracle, blind_tail):
+    """The symmetric option end to end at n = 1000: paired gain steps that rebuild only the rows Sigma(c, .), predictions
+    that keep up rows 1, 2 only (the tiles on and above the diagonal are the covariance between flushes), mirrored
+    flushes every 8 steps, 40 steps in two runs: 1e-9 against the CPU checker, and the covariance handed back is symmetric
+    to the bit outside the 32 x 32 diagonal squares.  blind_tail: the last steps see no landmark -- predictions behind the
+    last flush, whose column entries the run has to restore before it returns."""
     B, n, T = 3, 1000, 40
     cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=321, half_extent=8.0, min_spacing=0.2, max_visible_dis=2.0, vmax=2)
     log = synth.make_known_log(cfg)
+    if blind_tail:
+        log.lm_idx[T - blind_tail:] = -1
+        log.lm_idx[17:19] = -1           # (and the steps in front of a run boundary)
     bt = hip.BatchEKF(B, n)
     bt.set_update_mode(16, symmetric_gather=True)
     bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
-    bt.run_known()
-    assert bt.form_counts()["flush_mirrored"] >= 5
+    bt.run_known(0, 19)
+    c = bt.cov(1)
+    assert np.array_equal(c[32:, 1], c[1, 32:]) and np.array_equal(c[32:, 2], c[2, 32:])
+    bt.run_known(19, T)
+    assert bt.form_counts()["flush_mirrored"] >= 4
     ref_s, ref_c, _ = oracle.batch_run_known(log, oracle.STRUCTURED, want_cov=True, fast=False)
     tile = np.arange(3 + 2 * n) // 32
     above = tile[:, None] < tile[None, :]
