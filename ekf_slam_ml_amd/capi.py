@@ -386,7 +386,8 @@ class EKF_SLAM:
         return {"stream_ms": ms[0], "stream_launches": ln[0], "score_ms": ms[1], "score_launches": ln[1]}
 
     def set_update_mode(self, max_pending_corrections=0, symmetric_gather=False):
-        """0 = eager covariance stream per correction; k > 0 = delayed rank-2k update (flush every k)."""
+        """0 = eager covariance stream per correction; k > 0 = delayed rank-2k update (flush every k); symmetric_gather:
+        the opt-in symmetric option (Sigma H^T taken as (H Sigma)^T, mirrored flush) -- see ekf_set_update_mode"""
         _check(self._lib.ekf_set_update_mode(self._h, int(max_pending_corrections), int(symmetric_gather)))
 
 

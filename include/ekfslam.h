@@ -334,10 +334,19 @@ ekf_status ekf_batch_mc_stats(ekf_batch_handle hb, int t, double out[6]);
  * A single filter's data_association() stays delayed too: the Mahalanobis scores are taken against Sigma_base minus
  * the pending pairs, the winner's correction is appended like any other.  Same results to rounding (tested at 1e-9);
  * k is capped at 64.
- * symmetric_gather != 0 (delayed mode only): the gain step reads Sigma(c, r) where the reference reads
- * Sigma(r, c) for the five columns of Sigma*H^T -- a coalesced row read instead of a 16-KB-strided
- * column gather.  The reference never symmetrises Sigma, but (I - KH)Sigma keeps it symmetric to
- * rounding (measured asymmetry 1e-18 relative), so results still agree at 1e-9. */
+ * symmetric_gather != 0 (delayed mode only; opt-in, reported separately): the SYMMETRIC option.  The reference never
+ * symmetrises Sigma, but (I - KH)Sigma keeps it symmetric to rounding (measured asymmetry 1e-18 relative, SURVEY.md
+ * App. A2), and this option uses that:
+ *   - the gain step takes Sigma H^T as (H Sigma)^T: only the rows Sigma(c, .) are rebuilt, from coalesced base rows and
+ *     the V half of the pending store (no 16-KB-strided column gathers, half of the factor read);
+ *   - for N >= 256 the flush forms the tiles on and above the diagonal only and writes each tile above it twice, in place
+ *     and mirrored (4 N^2 bytes read + 8 N^2 written instead of 8 + 8; half of the multiply-adds): Sigma_base is then
+ *     symmetric to the bit outside the 32 x 32 diagonal squares;
+ *   - inside a known-association pool run the tiles on and above the diagonal ARE the covariance between flushes
+ *     (prediction() keeps up the rows 1, 2 and leaves their strided column images to the next mirroring flush; every run
+ *     returns with the full matrix restored).
+ * Not the reference's operands -- do not use it on a covariance that was set deliberately asymmetric -- but within the
+ * mode's 1e-9 (tests/test_gpu_delayed.py: 3.7e-13 on the bench configuration). */
 ekf_status ekf_set_update_mode(ekf_handle h, int max_pending_corrections, int symmetric_gather);
 ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections, int symmetric_gather);
 /* ---- dense general-F covariance propagation, fp32 on the matrix cores (BASELINE.json configs[3]) ----
