@@ -778,7 +778,7 @@ def main():
         lb.run_known(0, Ta)
         lb.set_call_fused(False)
         lb.set_known_counts(n)
-        lcfg = synth.config3(steps=Tu + Kdl)
+        lcfg = synth.config3(steps=Tu + 2 * Kdl)
         lcfg.filters, lcfg.first_filter_id, lcfg.n = Bl, rank * Bl, n
         lb.simulate_unknown_log(lcfg, lworld, jmax=J)
         lb.run_unknown(0, 1 + W)
@@ -825,6 +825,7 @@ def main():
         fence()
         dwall2, dcorr2, dsteps2 = shard.reduce_throughput(t1 - t0, float(sd2["corrections"]), float(sd2["filter_steps"]),
                                                           device=red_dev)
+        ref = None
         if rank == 0:
             nref = min(Bl, 8)
             ref = capi.BatchEKF(nref, n, device=local)
@@ -851,6 +852,27 @@ def main():
                 "note": "pools' data_association() in delayed mode: jmax = 8 pairs per step and filter stay pending across "
                         "steps (ekf_stepfused.hip, DELAYED), one flush per 4 steps instead of one pass per step; "
                         "tests/test_gpu_batch_unknown.py::test_delayed_data_association_for_pools"}
+        # ... and with the opt-in symmetric option (row-only reconstruction in the step kernel, mirrored flush), over the
+        # steps that follow; same side pool
+        lb.set_update_mode(kdl, symmetric_gather=True)
+        fence()
+        t0 = time.perf_counter()
+        sd3 = lb.run_unknown(Tu + Kdl, Tu + 2 * Kdl, time_kernels=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fence()
+        dwall3, _, dsteps3 = shard.reduce_throughput(t1 - t0, float(sd3["corrections"]), float(sd3["filter_steps"]), device=red_dev)
+        if rank == 0:
+            ref.run_unknown(Tu + Kdl, Tu + 2 * Kdl)
+            c_d, c_e = lb.cov(0), ref.cov(0)
+            out["unknown_association_large_prefix"]["delayed"]["symmetric"] = {
+                "value": dsteps3 / dwall3, "unit": "filter steps/s", "steps": Kdl,
+                "flush_avg_ms": sd3["rank2_ms"] / max(sd3["rank2_launches"], 1),
+                "flush_form": "mirrored (k_flush_sym)" if lb.form_counts()["flush_mirrored"] else "full",
+                "decisions_identical_to_eager": bool(np.array_equal(lb.decisions()[:, :nref], ref.decisions())),
+                "max_abs_state_diff_vs_eager": max(float(np.abs(lb.state(b) - ref.state(b)).max()) for b in range(nref)),
+                "max_rel_cov_diff_vs_eager": float(np.abs(c_d - c_e).max() / np.abs(c_e).max()),
+                "note": "opt-in symmetric option of ekf_set_update_mode; reported beside the default"}
             ref.close()
         lb.close()
     # The reference's own operating point at Monte-Carlo scale: configs[0] (n = 20, 1000 steps) for 8192 robots per

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
                                                                     unsigned long long* __restrict__ corr_counter,
                                                                     int* __restrict__ cnt_out, int zero_upto, int p0,
                                                                     int pair_rows, double* __restrict__ blocks_all,
-                                                                    const double* __restrict__ pred) {
+                                                                    const double* __restrict__ pred, int sym) {
     constexpr int kPairs = DELAYED ? kStepPendingPairs : kCallV;
     // cnt_out == nullptr: the final pass runs here (one workgroup streams its filter's covariance).  Otherwise the step
     // ends with the pairs in Uall / Vall (rows beyond the filter's pair count zero-filled up to `zero_upto` pairs) and
@@ -292,20 +292,22 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
         for (int r = tid; r < ld; r += kStepThreads) {
             double k0 = 0.0, k1 = 0.0, g0 = 0.0, g1 = 0.0;
             if (r < Nb) {
+                // sym (the symmetric option of the delayed mode, uniform): Sigma H^T is taken as (H Sigma)^T -- no column
+                // gather, no read of the U half of the pending pairs
                 double p[5], g[5];
-                gather_row5(Sg + (size_t)r * ld, lm, p);   // column gather (Sigma * H^T reads columns): three loads
+                if (!sym) gather_row5(Sg + (size_t)r * ld, lm, p);   // column gather (Sigma * H^T reads columns): three loads
 #pragma unroll
                 for (int k = 0; k < 5; k++) g[k] = Sg[(size_t)idx5(k, lm) * ld + r];   // row gather (H * Sigma reads rows)
                 // ... as they stand now: minus the pending pairs, in order (four pairs' values requested together)
                 auto fold_rc = [&](int v, const double (&f)[4]) {
 #pragma unroll
                     for (int k = 0; k < 5; k++) {
-                        p[k] = p[k] - (f[0] * sh_G5[v][k][0] + f[1] * sh_G5[v][k][1]);
+                        if (!sym) p[k] = p[k] - (f[0] * sh_G5[v][k][0] + f[1] * sh_G5[v][k][1]);
                         g[k] = g[k] - (sh_K5[v][k][0] * f[2] + sh_K5[v][k][1] * f[3]);
                     }
                 };
                 auto load_rc = [&](int v, double (&f)[4]) {
-                    f[0] = Ub[(size_t)(2 * v) * ld + r]; f[1] = Ub[(size_t)(2 * v + 1) * ld + r];
+                    if (!sym) { f[0] = Ub[(size_t)(2 * v) * ld + r]; f[1] = Ub[(size_t)(2 * v + 1) * ld + r]; }
                     f[2] = Vb[(size_t)(2 * v) * ld + r]; f[3] = Vb[(size_t)(2 * v + 1) * ld + r];
                 };
                 int v = 0;
@@ -320,6 +322,10 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
                     double f[4];
                     load_rc(v, f);
                     fold_rc(v, f);
+                }
+                if (sym) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) p[k] = g[k];
                 }
                 double sht0 = 0.0, sht1 = 0.0;
 #pragma unroll
@@ -442,14 +448,15 @@ void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int*
                               int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s,
                               int* cnt_out, int zero_upto, double* blocks) {
     hipLaunchKernelGGL(k_pool_step_unknown<false>, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
-                       assoc_out, U, V, corr_counter, cnt_out, zero_upto, 0, 2 * kCallV, blocks, nullptr);
+                       assoc_out, U, V, corr_counter, cnt_out, zero_upto, 0, 2 * kCallV, blocks, nullptr, 0);
 }
 
 void launch_pool_step_unknown_delayed(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                                       int* assoc_out, const Pending& pend, unsigned long long* corr_counter, int* cnt_scratch,
                                       double* blocks, const double* pred, hipStream_t s) {
     hipLaunchKernelGGL(k_pool_step_unknown<true>, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
-                       assoc_out, pend.U, pend.V, corr_counter, cnt_scratch, jmax, pend.count / 2, pend.cap, blocks, pred);
+                       assoc_out, pend.U, pend.V, corr_counter, cnt_scratch, jmax, pend.count / 2, pend.cap, blocks, pred,
+                       pend.symmetric != 0);
 }
 
 int step_pending_pairs_max() { return kStepPendingPairs; }
