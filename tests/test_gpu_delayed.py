@@ -333,8 +333,10 @@ def test_paired_delayed_gain_steps_random_shapes(hip, oracle):
         assert_parity(outs[0][0][0], outs[0][1][0], o.state, o.cov, FP64_TOL, f"shape {idx} vs checker")
 
 
-def test_delayed_at_the_million_steps_configuration(hip, oracle):
-    """The exact configuration of bench.py's >= 1e6 update steps/s leg (ekf_slam.cpp:178-192 at n = 1000): k = 32
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_delayed_at_the_million_steps_configuration(hip, oracle, symmetric):
+    """(symmetric: the same run with the opt-in symmetric option -- both flushes mirrored, row-only gain steps.)
+    The exact configuration of bench.py's >= 1e6 update steps/s leg (ekf_slam.cpp:178-192 at n = 1000): k = 32
     corrections per flush, the two corrections of a step in one gain launch (k_gain_delayed_pair), and a pool big enough
     (B = 128: 1024 strip workgroups) that launch_flush takes the strip form BY ITSELF at 64 pending vectors -- asserted
     through the form counters, not forced.  17 steps = 34 corrections per filter: one automatic flush at 32 (strip form)
@@ -343,13 +345,16 @@ def test_delayed_at_the_million_steps_configuration(hip, oracle):
     log = synth.make_known_log(synth.config5(filters=B, steps=T, n=n))
     assert ((log.lm_idx[1:] >= 0).sum(axis=2) == 2).all()   # V = 2 everywhere: every step is one paired launch
     bt = hip.BatchEKF(B, n)
-    bt.set_update_mode(k)
+    bt.set_update_mode(k, symmetric_gather=symmetric)
     assert bt.forms == hip.FORMS_DEFAULT                    # nothing forced
     bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
     st = bt.run_known(0, T, time_kernels=True)
     assert st["corrections"] == B * 34 and st["rank2_launches"] == 2
     fc = bt.form_counts()
-    assert fc["flush_strip"] == 1 and fc["flush_plain"] == 1 and fc["gain_pairs"] == T - 1, fc
+    if symmetric:
+        assert fc["flush_mirrored"] == 2 and fc["flush_strip"] + fc["flush_plain"] == 0 and fc["gain_pairs"] == T - 1, fc
+    else:
+        assert fc["flush_strip"] == 1 and fc["flush_plain"] == 1 and fc["gain_pairs"] == T - 1, fc
     for b in (0, 61, B - 1):
         o = oracle.OracleEKF(n, oracle.STRUCTURED)
         for t in range(T):
