@@ -137,3 +137,21 @@ def test_four_ranks_with_unequal_shards():
     # side legs are not run at N > 1
     for key in ("call_fused_update", "active_set_update", "unknown_association", "small_map_monte_carlo", "configs_1"):
         assert key not in d, key
+
+
+def test_two_ranks_run_the_delayed_legs():
+    """At N > 1 the job runs the contract leg plus the delayed leg and its symmetric variant: every rank takes part in their
+    reductions (no rank-0-only collective), and the aggregate counts both ranks' corrections."""
+    env = dict(os.environ, EKF_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    args = ["--steps", "4", "--warmup", "1", "--filters", "40", "--landmarks", "300", "--delayed-k", "4", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2"] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    dl = d["delayed_update"]
+    assert d["n_gpus"] == 2 and dl["steps"] == 4 and dl["flushes"] == 2
+    assert abs(dl["value"] * dl["ms_per_step"] * 1e-3 / (2 * 40 * 2) - 1.0) < 1e-9       # both ranks' filters, 2 corrections each
+    assert dl["max_abs_state_diff_vs_eager"] < 1e-9 and dl["symmetric"]["max_abs_state_diff_vs_eager"] < 1e-9
+    assert dl["symmetric"]["value"] > 0 and dl["symmetric"]["flush_form"].startswith("mirrored")
+
