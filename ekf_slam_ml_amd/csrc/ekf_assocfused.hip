@@ -27,20 +27,27 @@ constexpr int kAssocLandmarks = 64;    // ... around 64 landmarks (small workgro
 __global__ __launch_bounds__(64) void k_assoc_score(PoolView pv, double mx, double my,
                                                     const AssocRec* __restrict__ assoc_in, double* __restrict__ scores,
                                                     double* __restrict__ terms, const double* __restrict__ Ub,
-                                                    const double* __restrict__ Vb, int pc) {
+                                                    const double* __restrict__ Vb, int pc, double* __restrict__ blk) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int ld = pv.ld;
     const double* __restrict__ Sg = pv.sigma;
     const double* __restrict__ st = pv.state;
     const int M = assoc_in[0].known_count;
-    if (i >= M || i >= pv.n) return;
-    MeasTerms m;
-    measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, st[0], st[1], st[2], m);   // fresh pose, :219-221
+    if (i >= pv.n || (i >= M && !blk)) return;
     double S55[5][5], S[2][2], Si[2][2];
 #pragma unroll
     for (int k = 0; k < 5; k++)
 #pragma unroll
         for (int l = 0; l < 5; l++) S55[k][l] = Sg[(size_t)idx5(k, i) * ld + idx5(l, i)];
+    // blk ([25][n], the reading launches' block cache): every landmark's block as stored -- the launches of the pass keep
+    // it current by folding each new pair in (undiscovered landmarks too: their K = G = 0 leaves their part untouched)
+    if (blk && pc == 0) {
+#pragma unroll
+        for (int e = 0; e < 25; e++) blk[(size_t)e * pv.n + i] = S55[e / 5][e % 5];
+    }
+    if (i >= M) return;
+    MeasTerms m;
+    measurement_terms(st[2 * i + 3], st[2 * i + 4], mx, my, st[0], st[1], st[2], m);   // fresh pose, :219-221
     for (int v = 0; v < pc; v++) {   // ... as they stand NOW: minus the pending pairs of the call, in order
         double kr[5][2], gc[5][2];
 #pragma unroll
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
     AssocRec* __restrict__ assoc_next, int* __restrict__ assoc_out_j, double* __restrict__ state_out, double* __restrict__ Uall,
     double* __restrict__ Vall, int* __restrict__ cnt_out, int pc, int Nb, int zero_upto, int m_bound,
     const double* __restrict__ scores, const double* __restrict__ terms, double* __restrict__ scores_out,
-    double* __restrict__ terms_out, long long* __restrict__ trace) {
+    double* __restrict__ terms_out, long long* __restrict__ trace, double* __restrict__ blk) {
     const int tid = threadIdx.x;
     const int n = pv.n, N = pv.N, ld = pv.ld;
     // diagnostics (ekf_phase_trace): lane 0 of wave B of workgroup 0 stamps the 100 MHz wall clock, 16 slots per reading
@@ -170,7 +177,10 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
     const double st_r = st[rl];
     const bool scorer = wB && has_next && li < n;   // (whether li < known count after the decision is seen later)
     double S55[5][5];
-    if (scorer) {
+    if (scorer && blk) {   // the block as the previous launch (or the scoring launch) left it: current, coalesced
+#pragma unroll
+        for (int e = 0; e < 25; e++) S55[e / 5][e % 5] = blk[(size_t)e * n + li];
+    } else if (scorer) {
 #pragma unroll
         for (int v = 0; v < kCallV - 1; v++) {
             const int vc = v < pc ? v : 0;
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
     // (wave B; the pose values of the pairs are read straight from the factor rows: wave-uniform addresses).  Placed
     // behind the requests of step 3 so that it runs while they are in flight.
     auto pending_block = [&]() {
-        if (scorer) {
+        if (scorer && !blk) {   // (with the block cache there is nothing to bring up to date)
 #pragma unroll
             for (int v = 0; v < kCallV - 1; v++)
                 if (v < pc) {   // (uniform)
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
     if (wP && lane < 3) { sh_Kp[lane][0] = k0; sh_Kp[lane][1] = k1; sh_Gp[lane][0] = g0; sh_Gp[lane][1] = g1; sh_pose[lane] = so; }
     __syncthreads();
     AR_TR(8);
-    if (!scorer || li >= Mn) return;
+    if (!scorer || (li >= Mn && !blk)) return;
     if (corr) {   // ... minus reading j's own pair
         double kr[5][2], gc[5][2];
 #pragma unroll
@@ -380,7 +390,12 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
         for (int k = 0; k < 5; k++)
 #pragma unroll
             for (int l = 0; l < 5; l++) S55[k][l] = S55[k][l] - (kr[k][0] * gc[l][0] + kr[k][1] * gc[l][1]);
+        if (blk) {   // (thread-private entries: the next launch's loads follow this launch in stream order)
+#pragma unroll
+            for (int e = 0; e < 25; e++) blk[(size_t)e * n + li] = S55[e / 5][e % 5];
+        }
     }
+    if (li >= Mn) return;
     AR_TR(9);
     MeasTerms m;
     m.z0 = sh_z[0]; m.z1 = sh_z[1];
@@ -757,19 +772,22 @@ void launch_assoc_call(const PoolView& pv, const AssocCallArgs& a, int carried, 
 }
 
 void launch_assoc_score(const PoolView& pv, double mx, double my, const AssocRec* assoc_in, const double* U, const double* V,
-                        int pc, int m_bound, double* scores, double* terms, hipStream_t s) {
-    if (m_bound > 0)
-        hipLaunchKernelGGL(k_assoc_score, dim3((m_bound + 63) / 64), dim3(64), 0, s, pv, mx, my, assoc_in, scores, terms, U, V, pc);
+                        int pc, int m_bound, double* scores, double* terms, hipStream_t s, double* blk) {
+    const int cover = blk ? pv.n : m_bound;   // with the block cache: every landmark's block is taken, the known ones scored
+    if (cover > 0)
+        hipLaunchKernelGGL(k_assoc_score, dim3((cover + 63) / 64), dim3(64), 0, s, pv, mx, my, assoc_in, scores, terms, U, V, pc,
+                           blk);
 }
 
 void launch_assoc_reading(const PoolView& pv, double mx, double my, int has_next, double mxn, double myn,
                           const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j, double* state_out, double* U,
                           double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound, const double* scores,
-                          const double* terms, double* scores_out, double* terms_out, hipStream_t s, long long* trace) {
+                          const double* terms, double* scores_out, double* terms_out, hipStream_t s, long long* trace,
+                          double* blk) {
     const int landmarks = (pv.ld - 3 + 1) / 2;   // owners of every index of the padded row beyond the pose
     hipLaunchKernelGGL(k_assoc_reading, dim3((landmarks + kAssocLandmarks - 1) / kAssocLandmarks), dim3(kAssocThreads),
                        0, s, pv, mx, my, has_next, mxn, myn, assoc_in, assoc_next, assoc_out_j, state_out, U, V, cnt_out, pc, Nb,
-                       zero_upto, m_bound, scores, terms, scores_out, terms_out, trace);
+                       zero_upto, m_bound, scores, terms, scores_out, terms_out, trace, blk);
 }
 
 }  // namespace ekf

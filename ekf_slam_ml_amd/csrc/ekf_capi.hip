@@ -345,6 +345,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
             EKFC(P.dalloc(&P.terms2, (size_t)(n > 0 ? n : 1) * 16));
             EKFC(P.dalloc(&P.scores2, (size_t)(n > 0 ? n : 1)));
         }
+        EKFC(P.ensure_blk_cache());   // every landmark's 5 x 5 block, kept current from reading to reading
         P.alt_synced = false;
         auto m_bound = [&](int j) { return known_count + j < n ? known_count + j : n; };   // known count in front of reading j
         for (int j0 = 0; j0 < J; j0 += ekf::kCallV) {
@@ -353,7 +354,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
             double *sc_in = P.scores, *tm_in = P.terms, *sc_out = P.scores2, *tm_out = P.terms2;
             EKFC(P.prof_begin(1));
             ekf::launch_assoc_score(P.pv, meas_xy[2 * j0], meas_xy[2 * j0 + 1], P.pv.assoc, P.cf_U, P.cf_V, 0, m_bound(j0), sc_in,
-                                    tm_in, P.stream);
+                                    tm_in, P.stream, P.blk_cache);
             EKFC(P.prof_end());
             for (int jj = 0; jj < jc; jj++) {
                 const int j = j0 + jj;
@@ -363,7 +364,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
                                           has_next ? meas_xy[2 * j + 3] : 0.0, P.pv.assoc, P.assoc_alt, P.assoc_out_dev + j,
                                           P.cf_state, P.cf_U, P.cf_V, P.cf_cnt, jj, active_dim(j),
                                           jj == jc - 1 ? ekf::rank2v_round_count(jc) : 0, m_bound(j), sc_in, tm_in, sc_out, tm_out,
-                                          P.stream, P.phase_trace);
+                                          P.stream, P.phase_trace, P.blk_cache);
                 EKFC(P.prof_end());
                 std::swap(P.pv.state, P.cf_state);
                 std::swap(P.pv.assoc, P.assoc_alt);

@@ -508,12 +508,12 @@ void launch_rank2v(const PoolView& pv, const double* U, const double* V, const i
 // m_bound: host bound of the known count in front of the reading.  Nb: active dimension of the reading (discovered prefix).  The caller
 // ends the pass with launch_rank2v.
 void launch_assoc_score(const PoolView& pv, double mx, double my, const AssocRec* assoc_in, const double* U, const double* V,
-                        int pc, int m_bound, double* scores, double* terms, hipStream_t s);
+                        int pc, int m_bound, double* scores, double* terms, hipStream_t s, double* blk = nullptr);
 void launch_assoc_reading(const PoolView& pv, double mx, double my, int has_next, double mxn, double myn,
                           const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j, double* state_out, double* U,
                           double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound, const double* scores,
                           const double* terms, double* scores_out, double* terms_out, hipStream_t s,
-                          long long* trace = nullptr);
+                          long long* trace = nullptr, double* blk = nullptr);
 // A whole data_association() call (<= kCallV readings) of a single filter in ONE launch while the discovered part of the
 // map fits one workgroup (`carried` >= max(known_count + J, touched_hwm) landmarks, <= assoc_call_capacity()): a thread per
 // landmark keeps its block of Sigma current in registers.  In place on pv.state / pv.assoc; the pairs go to U / V, the caller
