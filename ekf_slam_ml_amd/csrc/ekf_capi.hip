@@ -1,5 +1,7 @@
 // ekf_capi.hip -- C ABI of include/ekfslam.h, single-filter entry points: the rigid2d::EKF_SLAM call surface
 // (create / clone / prediction / measurement / data_association / getters) and its mode switches.
+#include <atomic>
+
 #include "ekf_runtime.hpp"
 
 using namespace ekfrt;
@@ -204,7 +206,21 @@ static int assoc_call_fused_min_dim() {
 static ekf_status associate_finish(Pool& P, int known_count, int J, uint8_t* known, int* assoc_out) {
     const int n = P.pv.n;
     ekf::AssocRec rec;
-    if (P.assoc_block) {   // records and decisions in one block: one copy, one synchronisation
+    if (P.pub_host) {   // record and decisions through mapped host memory: the host waits for the sequence number only
+        EKFC(P.publish_assoc(J));   // (callers with a covariance pass behind the last decision have published in front of it)
+        P.pub_sent = false;
+        volatile unsigned* seq = reinterpret_cast<volatile unsigned*>(P.pub_host + 32);
+        for (unsigned spins = 1; *seq != P.pub_seq; spins++) {
+            if ((spins & 0xFFFF) == 0 && hipStreamQuery(P.stream) != hipErrorNotReady) {
+                // the stream has drained (or failed): the number must be there now, or never will be
+                HIPC(hipStreamSynchronize(P.stream));
+                if (*seq != P.pub_seq) return fail(EKF_ERR_HIP, "data_association: the result was not published");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(&rec, P.pub_host, sizeof(rec));
+        if (assoc_out) std::memcpy(assoc_out, P.pub_host + Pool::kAssocDecOff, sizeof(int) * (size_t)J);
+    } else if (P.assoc_block) {   // records and decisions in one block: one copy, one synchronisation
         const size_t bytes = Pool::kAssocDecOff + sizeof(int) * (size_t)J;
         EKFC(P.stage_out.reserve(bytes));
         HIPC(hipMemcpyAsync(P.stage_out.host, P.assoc_block, bytes, hipMemcpyDeviceToHost, P.stream));
@@ -237,6 +253,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     if (J == 0) return EKF_OK;
     const bool delayed = P.pend_cap > 0;   // delayed mode: scores and gains against Sigma_base minus the pending pairs
     EKFC(P.ensure_meas_capacity(J));
+    P.pub_sent = false;
     if (!delayed && P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && J <= ekf::kSmallInlineJ) {
         // small map: the whole call (and the prediction() before it) in one LDS-resident launch, measurements by value
         P.alt_synced = false;
@@ -323,6 +340,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
                 ekf::launch_assoc_call(P.pv, ca, carried, P.assoc_out_dev + j0, P.cf_U, P.cf_V, P.cf_cnt, ekf::rank2v_round_count(jc),
                                        P.stream, P.phase_trace);
                 EKFC(P.prof_end());
+                if (j0 + jc >= J) EKFC(P.publish_assoc(J));   // the decisions are final: the host need not wait for the pass
                 ekf::PoolView view = P.pv;
                 view.N = active_dim(j0 + jc - 1);
                 EKFC(P.prof_begin(0));
@@ -371,6 +389,7 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
                 std::swap(sc_in, sc_out);
                 std::swap(tm_in, tm_out);
             }
+            if (j0 + jc >= J) EKFC(P.publish_assoc(J));   // the decisions are final: the host need not wait for the pass
             ekf::PoolView view = P.pv;
             view.N = active_dim(j0 + jc - 1);
             EKFC(P.prof_begin(0));

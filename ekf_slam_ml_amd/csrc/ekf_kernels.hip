@@ -845,6 +845,23 @@ __global__ void k_gather_poses(PoolView pv, double* out) {
 
 // ---- launchers -------------------------------------------------------------------------------
 
+// The result of a data_association() call handed to the host without a copy engine and without a stream synchronisation
+// (measured, tools/micro/d2h_latency.hip: kernel + hipMemcpyAsync + hipStreamSynchronize 15.4 us, kernel that writes mapped
+// host memory + a host spin on a flag word 6.8 us): record and decisions first, system-scope fence, then the sequence number.
+__global__ __launch_bounds__(64) void k_publish_assoc(const AssocRec* __restrict__ rec, const int* __restrict__ decisions, int J,
+                                                      char* host, unsigned seq) {
+    int* hd = reinterpret_cast<int*>(host + 64);
+    for (int j = threadIdx.x; j < J; j += 64) hd[j] = decisions[j];
+    if (threadIdx.x == 0) *reinterpret_cast<AssocRec*>(host) = rec[0];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(host + 32) = seq;
+}
+
+void launch_publish_assoc(const AssocRec* rec, const int* decisions, int J, char* host, unsigned seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_publish_assoc, dim3(1), dim3(64), 0, s, rec, decisions, J, host, seq);
+}
+
 void launch_init(const PoolView& pv, hipStream_t s) {
     dim3 grid((pv.N + kInitRows - 1) / kInitRows, pv.B);
     hipLaunchKernelGGL(k_init, grid, dim3(256), 0, s, pv);

@@ -384,6 +384,9 @@ struct Rank2Tuning {
 };
 
 void launch_init(const PoolView& pv, hipStream_t s);
+// data_association() of a single filter ends here: the association record and the call's J decisions go to mapped host
+// memory, then the sequence number (host layout: [record 32 B | seq 4 B | .. | decisions from byte 64])
+void launch_publish_assoc(const AssocRec* rec, const int* decisions, int J, char* host, unsigned seq, hipStream_t s);
 // prediction(): twist = imm (dtheta, dx) when twist_dev == nullptr, else twist_dev[b*2 + {0,1}]
 void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, double dx, const Pending& pend,
                     hipStream_t s, double* pred_out = nullptr /* [B][2]: (a10, a20) of At, for the block cache */);

@@ -493,6 +493,8 @@ struct Pool {
             if (p) (void)hipFree(p);
         stage_in.release();
         stage_out.release();
+        if (pub_host) (void)hipHostFree(pub_host);
+        pub_host = nullptr;
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -593,6 +595,17 @@ struct Pool {
     // ONE block -- [record | record | decisions] -- so that data_association() ends with one device-to-host copy.
     char* assoc_block = nullptr;
     static constexpr size_t kAssocRecSlot = 32, kAssocDecOff = 64;
+    // ... and its mirror in mapped host memory ([record | sequence number | decisions]): k_publish_assoc writes it, the
+    // host spins on the sequence number -- no copy engine, no stream synchronisation at the end of a call
+    char* pub_host = nullptr;
+    unsigned pub_seq = 0;
+    bool pub_sent = false;
+    ekf_status publish_assoc(int J) {
+        if (!pub_host || pub_sent) return EKF_OK;
+        ekf::launch_publish_assoc(pv.assoc, assoc_out_dev, J, pub_host, ++pub_seq, stream);
+        pub_sent = true;
+        return EKF_OK;
+    }
     ekf_status ensure_meas_capacity(int J) {
         if (J <= jcap) return EKF_OK;
         HIPC(hipStreamSynchronize(stream));
@@ -614,6 +627,10 @@ struct Pool {
                 if (assoc_alt) HIPC(hipFree(assoc_alt));
             }
             assoc_block = blk;
+            if (pub_host) HIPC(hipHostFree(pub_host));
+            pub_host = nullptr;
+            HIPC(hipHostMalloc((void**)&pub_host, kAssocDecOff + sizeof(int) * (size_t)cap, hipHostMallocMapped));
+            std::memset(pub_host, 0, kAssocDecOff);
             pv.assoc = reinterpret_cast<ekf::AssocRec*>(blk);
             assoc_alt = reinterpret_cast<ekf::AssocRec*>(blk + kAssocRecSlot);
             assoc_out_dev = reinterpret_cast<int*>(blk + kAssocDecOff);
