@@ -131,7 +131,8 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
     AssocRec* __restrict__ assoc_next, int* __restrict__ assoc_out_j, double* __restrict__ state_out, double* __restrict__ Uall,
     double* __restrict__ Vall, int* __restrict__ cnt_out, int pc, int Nb, int zero_upto, int m_bound,
     const double* __restrict__ scores, const double* __restrict__ terms, double* __restrict__ scores_out,
-    double* __restrict__ terms_out, long long* __restrict__ trace, double* __restrict__ blk) {
+    double* __restrict__ terms_out, long long* __restrict__ trace, double* __restrict__ blk, char* pub_host, int pub_j,
+    unsigned pub_seq) {
     const int tid = threadIdx.x;
     const int n = pv.n, N = pv.N, ld = pv.ld;
     // diagnostics (ekf_phase_trace): lane 0 of wave B of workgroup 0 stamps the 100 MHz wall clock, 16 slots per reading
@@ -263,6 +264,14 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
             rc.nu0 = 0.0; rc.nu1 = 0.0; rc.active = active; rc.lm = a.lm; rc.n_active = 0; rc.pad = 0;
             pv.rec[0] = rc;
             if (active) touch_landmark(pv, 0, idx);
+            if (pub_host) {   // the host's copy (see k_assoc_call): behind the call's last decision the record and the number
+                reinterpret_cast<int*>(pub_host + 64)[pub_j] = a.lm;
+                if (pub_seq) {
+                    *reinterpret_cast<AssocRec*>(pub_host) = a;
+                    __threadfence_system();
+                    *reinterpret_cast<volatile unsigned*>(pub_host + 32) = pub_seq;
+                }
+            }
         }
     }
     __syncthreads();
@@ -436,7 +445,8 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_assoc_call(PoolView pv, AssocCallArgs a, int* __restrict__ assoc_out,
                                                                     double* __restrict__ Uall, double* __restrict__ Vall,
                                                                     int* __restrict__ cnt_out, int zero_upto,
-                                                                    long long* __restrict__ trace) {
+                                                                    long long* __restrict__ trace, char* pub_host,
+                                                                    int pub_j0, unsigned pub_seq) {
     const int tid = threadIdx.x, lane = tid & 63;
     // diagnostics (ekf_phase_trace): thread 0 stamps the 100 MHz wall clock, 16 slots per reading (slot 15 of reading 0: start)
 #define AC_TR(j, k) do { if (trace && tid == 0) trace[(j) * 16 + (k)] = wall_clock64(); } while (0)
@@ -565,6 +575,18 @@ __global__ __launch_bounds__(THREADS) void k_assoc_call(PoolView pv, AssocCallAr
             sh_lm = active ? idx : -1;
             sh_new = is_new;
             assoc_out[j] = active ? idx : -1;
+            // The host's copy (mapped memory, see k_publish_assoc): the decision now, and behind the call's LAST decision the
+            // record and the sequence number -- the host goes on while this launch builds the last gain.
+            if (pub_host) {
+                reinterpret_cast<int*>(pub_host + 64)[pub_j0 + j] = active ? idx : -1;
+                if (pub_seq && j == a.J - 1) {
+                    AssocRec rec;
+                    rec.known_count = Mn; rec.lm = active ? idx : -1; rec.active = active; rec.pad = 0; rec.best = 0.0;
+                    *reinterpret_cast<AssocRec*>(pub_host) = rec;
+                    __threadfence_system();
+                    *reinterpret_cast<volatile unsigned*>(pub_host + 32) = pub_seq;
+                }
+            }
         }
         __syncthreads();
         AC_TR(j, 3);
@@ -763,12 +785,15 @@ __global__ __launch_bounds__(THREADS) void k_assoc_call(PoolView pv, AssocCallAr
 int assoc_call_capacity() { return kCallLandmarks; }
 
 void launch_assoc_call(const PoolView& pv, const AssocCallArgs& a, int carried, int* assoc_out, double* U, double* V,
-                       int* cnt_out, int zero_upto, hipStream_t s, long long* trace) {
+                       int* cnt_out, int zero_upto, hipStream_t s, long long* trace, char* pub_host, int pub_j0,
+                       unsigned pub_seq) {
     const int waves = (carried + 63) / 64 > 0 ? (carried + 63) / 64 : 1;
     if (waves <= 3)
-        hipLaunchKernelGGL(k_assoc_call<256>, dim3(1), dim3(64 * waves + 64), 0, s, pv, a, assoc_out, U, V, cnt_out, zero_upto, trace);
+        hipLaunchKernelGGL(k_assoc_call<256>, dim3(1), dim3(64 * waves + 64), 0, s, pv, a, assoc_out, U, V, cnt_out, zero_upto, trace,
+                           pub_host, pub_j0, pub_seq);
     else
-        hipLaunchKernelGGL(k_assoc_call<512>, dim3(1), dim3(64 * waves + 64), 0, s, pv, a, assoc_out, U, V, cnt_out, zero_upto, trace);
+        hipLaunchKernelGGL(k_assoc_call<512>, dim3(1), dim3(64 * waves + 64), 0, s, pv, a, assoc_out, U, V, cnt_out, zero_upto, trace,
+                           pub_host, pub_j0, pub_seq);
 }
 
 void launch_assoc_score(const PoolView& pv, double mx, double my, const AssocRec* assoc_in, const double* U, const double* V,
@@ -783,11 +808,11 @@ void launch_assoc_reading(const PoolView& pv, double mx, double my, int has_next
                           const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j, double* state_out, double* U,
                           double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound, const double* scores,
                           const double* terms, double* scores_out, double* terms_out, hipStream_t s, long long* trace,
-                          double* blk) {
+                          double* blk, char* pub_host, int pub_j, unsigned pub_seq) {
     const int landmarks = (pv.ld - 3 + 1) / 2;   // owners of every index of the padded row beyond the pose
     hipLaunchKernelGGL(k_assoc_reading, dim3((landmarks + kAssocLandmarks - 1) / kAssocLandmarks), dim3(kAssocThreads),
                        0, s, pv, mx, my, has_next, mxn, myn, assoc_in, assoc_next, assoc_out_j, state_out, U, V, cnt_out, pc, Nb,
-                       zero_upto, m_bound, scores, terms, scores_out, terms_out, trace, blk);
+                       zero_upto, m_bound, scores, terms, scores_out, terms_out, trace, blk, pub_host, pub_j, pub_seq);
 }
 
 }  // namespace ekf

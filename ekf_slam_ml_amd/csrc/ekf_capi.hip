@@ -337,10 +337,12 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
                 ca.touched_hwm = P.touched_hwm;
                 ca.active_prefix = P.active_prefix;
                 EKFC(P.prof_begin(1));
+                // (the launch writes its decisions to the host's mapped copy; the call's last launch also the record and the
+                // sequence number, behind its last decision: the host waits neither for the last gain nor for the pass)
+                const bool last = j0 + jc >= J;
                 ekf::launch_assoc_call(P.pv, ca, carried, P.assoc_out_dev + j0, P.cf_U, P.cf_V, P.cf_cnt, ekf::rank2v_round_count(jc),
-                                       P.stream, P.phase_trace);
+                                       P.stream, P.phase_trace, P.pub_host, j0, last && P.pub_host ? P.claim_pub_seq() : 0u);
                 EKFC(P.prof_end());
-                if (j0 + jc >= J) EKFC(P.publish_assoc(J));   // the decisions are final: the host need not wait for the pass
                 ekf::PoolView view = P.pv;
                 view.N = active_dim(j0 + jc - 1);
                 EKFC(P.prof_begin(0));
@@ -382,14 +384,14 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
                                           has_next ? meas_xy[2 * j + 3] : 0.0, P.pv.assoc, P.assoc_alt, P.assoc_out_dev + j,
                                           P.cf_state, P.cf_U, P.cf_V, P.cf_cnt, jj, active_dim(j),
                                           jj == jc - 1 ? ekf::rank2v_round_count(jc) : 0, m_bound(j), sc_in, tm_in, sc_out, tm_out,
-                                          P.stream, P.phase_trace, P.blk_cache);
+                                          P.stream, P.phase_trace, P.blk_cache, P.pub_host, j,
+                                          j == J - 1 && P.pub_host ? P.claim_pub_seq() : 0u);
                 EKFC(P.prof_end());
                 std::swap(P.pv.state, P.cf_state);
                 std::swap(P.pv.assoc, P.assoc_alt);
                 std::swap(sc_in, sc_out);
                 std::swap(tm_in, tm_out);
             }
-            if (j0 + jc >= J) EKFC(P.publish_assoc(J));   // the decisions are final: the host need not wait for the pass
             ekf::PoolView view = P.pv;
             view.N = active_dim(j0 + jc - 1);
             EKFC(P.prof_begin(0));

@@ -516,7 +516,8 @@ void launch_assoc_reading(const PoolView& pv, double mx, double my, int has_next
                           const AssocRec* assoc_in, AssocRec* assoc_next, int* assoc_out_j, double* state_out, double* U,
                           double* V, int* cnt_out, int pc, int Nb, int zero_upto, int m_bound, const double* scores,
                           const double* terms, double* scores_out, double* terms_out, hipStream_t s,
-                          long long* trace = nullptr, double* blk = nullptr);
+                          long long* trace = nullptr, double* blk = nullptr, char* pub_host = nullptr, int pub_j = 0,
+                          unsigned pub_seq = 0);
 // A whole data_association() call (<= kCallV readings) of a single filter in ONE launch while the discovered part of the
 // map fits one workgroup (`carried` >= max(known_count + J, touched_hwm) landmarks, <= assoc_call_capacity()): a thread per
 // landmark keeps its block of Sigma current in registers.  In place on pv.state / pv.assoc; the pairs go to U / V, the caller
@@ -530,7 +531,8 @@ struct AssocCallArgs {
 };
 int assoc_call_capacity();
 void launch_assoc_call(const PoolView& pv, const AssocCallArgs& a, int carried, int* assoc_out, double* U, double* V,
-                       int* cnt_out, int zero_upto, hipStream_t s, long long* trace = nullptr);
+                       int* cnt_out, int zero_upto, hipStream_t s, long long* trace = nullptr, char* pub_host = nullptr,
+                       int pub_j0 = 0, unsigned pub_seq = 0);
 int rank2v_round_count(int vcount);   // corrections per pass, rounded up to an instantiated count of k_rank2v
 
 // one step of an unknown-association log for every filter of a pool in ONE launch, any prefix size (ekf_stepfused.hip):

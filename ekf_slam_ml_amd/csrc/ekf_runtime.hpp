@@ -600,6 +600,8 @@ struct Pool {
     char* pub_host = nullptr;
     unsigned pub_seq = 0;
     bool pub_sent = false;
+    // a deciding kernel publishes by itself (k_assoc_call / k_assoc_reading): the number its last launch will write
+    unsigned claim_pub_seq() { pub_sent = true; return ++pub_seq; }
     ekf_status publish_assoc(int J) {
         if (!pub_host || pub_sent) return EKF_OK;
         ekf::launch_publish_assoc(pv.assoc, assoc_out_dev, J, pub_host, ++pub_seq, stream);
