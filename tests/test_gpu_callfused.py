@@ -222,3 +222,29 @@ def test_a_filter_full_of_nan_leaves_its_pool_neighbours_alone(hip, call_fused):
     assert np.isnan(res[0][0][2]).any() and np.isnan(res[0][1][2]).any() and not np.isnan(res[1][0][2]).any()
     for b in (0, 1, 3, 4):
         assert np.array_equal(res[0][0][b], res[1][0][b]) and np.array_equal(res[0][1][b], res[1][1][b]), f"filter {b}"
+
+
+@pytest.mark.parametrize("n,J", [(300, 100), (1000, 70), (150, 130)])
+def test_calls_with_more_than_64_readings(hip, n, J):
+    """data_association() calls that outgrow the 64-reading capacity (the decision block and its mapped host copy are
+    re-allocated) and span many passes of 8 readings: the call-fused forms (whole call / one launch per reading, decisions
+    published to the host's copy by the deciding launches themselves) against the per-reading form, which ends with the
+    separate publishing launch -- decisions, known_list, state and covariance bit for bit."""
+    world = synth.make_world(n, 10.0, 0.5, 5)
+    outs = []
+    for cf in (True, False):
+        f = hip.EKF_SLAM(n)
+        f.set_call_fused(cf)
+        known = np.zeros(n, dtype=np.uint8)
+        rng = np.random.default_rng(7)
+        decs = []
+        for _ in range(4):
+            f.prediction(np.array([0.02, 0.1]))
+            idx = rng.choice(n, size=J, replace=False)
+            decs.append(np.array(f.data_association(world[idx] + rng.normal(0, 0.01, size=(J, 2)), known)).copy())
+        outs.append((np.concatenate(decs), known.copy(), f.state.copy(), f.cov.copy()))
+        f.close()
+    assert outs[0][1].sum() > 100
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+
