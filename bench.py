@@ -70,6 +70,37 @@ def parse():
     return a
 
 
+LINE_BUDGET = 7500   # characters of the one JSON line (tests/test_host.py holds the committed line to it, too)
+_FULL_PRECISION = {"value", "ms_per_step", "achieved", "frac", "avg_launch_ms", "rank_ms_per_step_min", "rank_ms_per_step_max",
+                   "algorithmic_bytes_per_launch", "traffic", "declared_bytes_per_correction"}
+
+
+# computed (and used by the checks inside bench.py) but not printed: derivable from what is
+_DROP = {"scores_per_s", "measurements", "corrections", "score_launches", "steps_per_flush", "covariance_GBps", "parity_filters",
+         "known_landmarks_min", "corrections_per_launch", "kernel_launches", "fp64_check_rows", "touched_landmarks_max",
+         "hbm_bytes_per_gpu", "state_dim", "landmarks", "peak_nested", "achieved_GBps_on_declared_bytes", "launches_nested",
+         "active_dimension_max", "measurement_slots", "steps_timed", "corrections_per_step"}
+
+
+def compact(o, key=None, depth=0):
+    """Numbers only, short: every float below the top-level contract keys is rounded to 5 significant digits, the
+    Monte-Carlo blocks become [nees_mean, nees_max, rmse_xy, rmse_theta, mean_trace_pose_cov, frac_below_95pct(, step)]
+    lists.  The prose that used to travel in `note` / `sample` / `workload` lives in README.md ("Reading the bench line")."""
+    if isinstance(o, dict):
+        if "nees_mean" in o:
+            return [compact(v, None, depth + 1) for v in o.values()]
+        return {k: compact(v, k, depth + 1) for k, v in o.items() if not (depth >= 1 and k in _DROP)}
+    if isinstance(o, (list, tuple)):
+        return [compact(v, None, depth + 1) for v in o]
+    if isinstance(o, float):
+        if o != o or o in (float("inf"), float("-inf")):
+            return None
+        if depth <= 2 and key in _FULL_PRECISION:
+            return float(f"{o:.9g}")
+        return float(f"{o:.5g}")
+    return o
+
+
 def sha256_of(path):
     h = hashlib.sha256()
     with open(path, "rb") as f:
@@ -105,10 +136,8 @@ def cpu_baseline(sub, K, t_warm, cores, gpu_state):
     B = sub.twist.shape[1]
     return {"value": stats["corrections"] / stats["seconds"], "unit": "update steps/s", "cores": stats["threads"],
             "kind": "port",
-            "sample": f"{B} filters x {K} timed steps x 2 corrections at n={sub.cfg.n} "
-                      f"({stats['corrections']} corrections, {stats['seconds']:.1f} s): structured O(N^2) C "
-                      f"restatement (oracle/ekf_oracle.c mode 1, gcc -O3 -mavx2 -mfma, OpenMP over filters); the "
-                      f"reference's own dense Armadillo path is O(N^3) per correction and cannot be built here",
+            "sample": f"{B} filters (strided over the pool) x {K} steps x 2 corr, n={sub.cfg.n}, {stats['seconds']:.1f} s, "
+                      f"structured C port, OpenMP",
             "max_abs_state_diff_vs_gpu": float(np.abs(st - gpu_state).max())}
 
 
@@ -145,9 +174,8 @@ def leg_configs_1(device, cores, steps=2000, warm=100, want_cpu=True):
     dt, _, st_gpu = run(False)
     _, prof, _ = run(True)
     corr = int((log.lm_idx[warm:] >= 0).sum())
-    out = {"workload": f"BASELINE.json configs[1]: 1 filter, n={n} (N={N}), known association, {steps - warm} timed steps "
-                       f"after {warm} warm-up, one ekf_predict + ekf_measure_known per step through the C ABI (ctypes loop)",
-           "value": corr / dt, "unit": "update steps/s (landmark corrections)", "filter_steps_per_s": (steps - warm) / dt,
+    out = {"workload": f"configs[1]: 1 filter n={n} known, {steps - warm} steps via the C ABI",
+           "value": corr / dt, "unit": "update steps/s", "filter_steps_per_s": (steps - warm) / dt,
            "corrections_per_step": corr / (steps - warm), "us_per_correction": dt / corr * 1e6}
     kern_us = prof["stream_ms"] / max(prof["stream_launches"], 1) * 1e3
     # Two figures, never mixed: `contract` prices every correction at the eager stream's
@@ -158,17 +186,10 @@ def leg_configs_1(device, cores, steps=2000, warm=100, want_cpu=True):
     streamed_bytes = launches * 16.0 * N * N + (steps - warm) * 2 * 3 * 8.0 * N + corr * (2 * 2 * 8.0 * N + 2 * 4 * 8.0 * N)
     out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                        "achieved": streamed_bytes / dt / 1e9, "frac": streamed_bytes / dt / 1e9 / HBM_PEAK_GBS,
-                       "streamed_frac": streamed_bytes / dt / 1e9 / HBM_PEAK_GBS,
-                       "contract_GBps": corr / dt * bytes_corr / 1e9, "contract_frac": corr / dt * bytes_corr / 1e9 / HBM_PEAK_GBS,
-                       "traffic": None, "algorithmic_bytes_per_correction": bytes_corr,
-                       "streamed_bytes_per_correction": streamed_bytes / corr,
-                       "kernel_avg_us": kern_us, "kernel_launches": prof["stream_launches"],
+                       "contract_frac": corr / dt * bytes_corr / 1e9 / HBM_PEAK_GBS,
+                       "traffic": None, "kernel_avg_us": kern_us, "kernel_launches": prof["stream_launches"],
                        "corrections_per_launch": corr / launches,
-                       "in_kernel_GBps": bytes_corr / (kern_us * 1e-6) / 1e9,
-                       "note": "latency-bound, not bandwidth-bound (Sigma = 1.3 MB lives in L2): `achieved` / `frac` = bytes "
-                               "the launches really move / wall time; contract_* = corrections/s x 16 N^2 B (the eager "
-                               "stream's price per correction, which this path does not pay); in_kernel_GBps = 16 N^2 B of "
-                               "one pass / its HIP-event time (a second, instrumented pass)"}
+                       "in_kernel_GBps": bytes_corr / (kern_us * 1e-6) / 1e9}
     if want_cpu:
         from oracle import binding as ob  # checker / baseline only
         o = ob.OracleEKF(n, ob.STRUCTURED, fast=True)
@@ -185,13 +206,8 @@ def leg_configs_1(device, cores, steps=2000, warm=100, want_cpu=True):
         ddt = time.perf_counter() - t0
         dcorr = int((log.lm_idx[:dsteps] >= 0).sum())
         out["cpu_baseline"] = {"value": call / cdt, "unit": "update steps/s", "cores": 1, "kind": "port",
-                               "sample": f"the same {steps} steps ({call} corrections, {cdt:.2f} s) on the structured "
-                                         f"O(N^2) C restatement, one thread (a single filter is sequential)",
-                               "reference_algorithm_dense": {
-                                   "value": dcorr / max(ddt, 1e-9), "unit": "update steps/s", "cores": 1,
-                                   "sample": f"first {dsteps} steps ({dcorr} corrections, {ddt:.1f} s) of the dense-literal "
-                                             f"restatement = the reference's O(N^3) Armadillo expressions as plain loops "
-                                             f"(no BLAS in the image's C toolchain)"},
+                               "sample": f"same {steps} steps, {cdt:.2f} s, structured C port",
+                               "dense_literal": {"value": dcorr / max(ddt, 1e-9), "sample": f"{dsteps} steps, {ddt:.1f} s, O(N^3) loops"},
                                "max_abs_state_diff_vs_gpu": float(np.abs(o.state - st_gpu).max())}
     return out
 
@@ -209,8 +225,7 @@ def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
     log = synth.make_unknown_log(cfg)
     n, N = cfg.n, 3 + 2 * cfg.n
     meas = [log.meas_xy[t, 0, :log.count[t, 0]] for t in range(steps)]
-    out = {"workload": f"BASELINE.json configs[2]: 1 filter, n={n} (N={N}), unknown association, J<=8 shuffled readings per "
-                       f"step, one ekf_predict + ekf_associate per step through the C ABI (ctypes loop)"}
+    out = {"workload": f"configs[2]: 1 filter n={n} unknown, J<=8 per step via the C ABI"}
 
     # (a) discovery run (an untimed pass first: the path changes kernels as the map grows -- LDS-resident step kernel,
     # then two launches per reading -- and the first launch of every instantiation loads its code object)
@@ -225,18 +240,21 @@ def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
         t0 = time.perf_counter()
         nm = nc = 0
         scores = 0
+        decs = []
         for t in range(warm, steps):
             kc = int(known.sum())
             f.prediction(log.twist[t, 0]); a = f.data_association(meas[t], known)
             nm += len(a); nc += int((a >= 0).sum())
             scores += len(a) * kc  # lower bound (known_count grows inside the call)
+            decs.append(a)
         f.sync()
         dt = time.perf_counter() - t0
+        st = f.state
         f.close()
-        return dt, nm, nc, scores, known
+        return dt, nm, nc, scores, known, decs, st
 
     discover()
-    dt, nm, nc, scores, known = discover()
+    dt, nm, nc, scores, known, gpu_decs, gpu_disc_state = discover()
     out["discovery"] = {"value": (steps - warm) / dt, "unit": "filter steps/s", "measurements_per_s": nm / dt,
                         "corrections_per_s": nc / dt, "scores_per_s": scores / dt, "known_landmarks_end": int(known.sum()),
                         "steps": steps - warm}
@@ -268,9 +286,11 @@ def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
     kn = np.ones(n, dtype=np.uint8)
     t0 = time.perf_counter()
     nm = nc = 0
+    full_decs = []
     for t in range(full_steps):
         g.prediction(log.twist[t, 0]); a = g.data_association(meas[t], kn)
         nm += len(a); nc += int((a >= 0).sum())
+        full_decs.append(a)
     g.sync()
     dt = time.perf_counter() - t0
     st_gpu = g.state
@@ -283,24 +303,16 @@ def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
     bytes_corr = 16.0 * N * N
     k_us = prof["stream_ms"] / max(prof["stream_launches"], 1) * 1e3
     s_us = prof["score_ms"] / max(prof["score_launches"], 1) * 1e3
-    out["full_map"] = {"value": nm / dt, "unit": "measurements/s (each scored against all 1000 landmarks)",
+    out["full_map"] = {"value": nm / dt, "unit": "measurements/s",
                        "filter_steps_per_s": full_steps / dt, "scores_per_s": nm * n / dt, "corrections_per_s": nc / dt,
                        "known_landmarks": n, "measurements": nm, "corrections": nc, "steps": full_steps,
                        "score_kernel_avg_us": s_us, "score_launches": prof["score_launches"],
                        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                     "achieved": prof["stream_launches"] * bytes_corr / dt / 1e9,
                                     "frac": prof["stream_launches"] * bytes_corr / dt / 1e9 / HBM_PEAK_GBS,
-                                    "streamed_frac": prof["stream_launches"] * bytes_corr / dt / 1e9 / HBM_PEAK_GBS,
-                                    "contract_GBps": nc / dt * bytes_corr / 1e9,
                                     "contract_frac": nc / dt * bytes_corr / 1e9 / HBM_PEAK_GBS,
-                                    "traffic": None, "algorithmic_bytes_per_correction": bytes_corr,
-                                    "kernel_avg_us": k_us, "kernel_launches": prof["stream_launches"],
-                                    "corrections_per_launch": nc / max(prof["stream_launches"], 1),
-                                    "in_kernel_GBps": bytes_corr / (k_us * 1e-6) / 1e9,
-                                    "note": "one launch per reading (decision + gain against the stored covariance minus the "
-                                            "call's pending pairs) and ONE pass over Sigma per call: `achieved` / `frac` = "
-                                            "passes x 16 N^2 B / wall time (what the launches move); contract_* = "
-                                            "corrections/s x 16 N^2 B; Sigma = 32 MB is served by the Infinity Cache"}}
+                                    "traffic": None, "kernel_avg_us": k_us, "kernel_launches": prof["stream_launches"],
+                                    "in_kernel_GBps": bytes_corr / (k_us * 1e-6) / 1e9}}
     if want_cpu:
         from oracle import binding as ob  # checker / baseline only
         o = ob.OracleEKF(n, ob.STRUCTURED, fast=True)
@@ -308,17 +320,35 @@ def leg_configs_2(device, cores, steps=2000, full_steps=300, want_cpu=True):
         o.set_init_flag(1)
         ko = np.ones(n, dtype=np.uint8)
         csteps = full_steps
+        # decision margins of the run (the checker records, for every scored (reading, landmark) pair, the relative distance
+        # of the score to the gates 10.0 / 1.0 of ekf_slam.cpp:293,330 and the winner-to-runner-up gap, :305-309): the only
+        # place where another summation order could change a result by more than rounding
+        mg = ob.new_margins()
         t0 = time.perf_counter()
         cm = 0
+        same = True
         for t in range(csteps):
-            o.prediction(*log.twist[t, 0]); b = o.data_association(meas[t], ko)
+            o.prediction(*log.twist[t, 0]); b = o.data_association(meas[t], ko, mg)
             cm += len(b)
+            same = same and bool(np.array_equal(b, full_decs[t]))
         cdt = time.perf_counter() - t0
+        out["full_map"]["min_gate_margin"] = float(mg[:3].min())
+        out["full_map"]["decisions_identical_to_cpu_port"] = same
+        # ... and of the discovery run (replayed on the checker from the start)
+        od = ob.OracleEKF(n, ob.STRUCTURED, fast=True)
+        kd = np.zeros(n, dtype=np.uint8)
+        mgd = ob.new_margins()
+        same = True
+        for t in range(steps):
+            od.prediction(*log.twist[t, 0]); b = od.data_association(meas[t], kd, mgd)
+            if t >= warm:
+                same = same and bool(np.array_equal(b, gpu_decs[t - warm]))
+        out["discovery"]["min_gate_margin"] = float(mgd[:3].min())
+        out["discovery"]["decisions_identical_to_cpu_port"] = same
+        out["discovery"]["max_abs_state_diff_vs_cpu_port"] = float(np.abs(od.state - gpu_disc_state).max())
         out["full_map"]["cpu_baseline"] = {
             "value": cm / cdt, "unit": "measurements/s", "cores": 1, "kind": "port",
-            "sample": f"first {csteps} steps ({cm} measurements x {n} scores + corrections, {cdt:.1f} s) from the GPU filter's "
-                      f"post-mapping state on the structured C restatement (O(1) per score, O(N^2) per correction), one "
-                      f"thread; the reference scores with a dense 2xN x NxN product per pair (ekf_slam.cpp:267)"}
+            "sample": f"same {csteps} steps, {cdt:.1f} s, structured C port"}
         if csteps == full_steps:
             out["full_map"]["cpu_baseline"]["max_abs_state_diff_vs_gpu"] = float(np.abs(o.state - st_gpu).max())
     return out
@@ -351,15 +381,11 @@ def leg_configs_3(device, cores, N=10003, iters=5, want_cpu=True):
     med = float(np.median(ms))
     flop = 4.0 * float(N) ** 3
     tf = flop / (med * 1e-3) / 1e12
-    out = {"workload": f"BASELINE.json configs[3]: Sigma <- F Sigma F^T + Q, dense random F, N={N} (n=5000), fp32 on "
-                       f"v_mfma_f32_32x32x2_f32, two products per propagation (ekf_slam.cpp:101-102)",
+    out = {"workload": f"configs[3]: dense F Sigma F^T + Q, N={N}, fp32 MFMA",
            "value": 1e3 / med, "unit": "propagations/s", "ms_per_propagation": med, "dtype": "f32",
-           "launch": info, "fp64_check_rel_err": err, "fp64_check_rows": [int(r) for r in rows],
+           "launch": info, "fp64_check_rel_err": err, "fp64_check_rows": len(rows),
            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF, "achieved": tf,
-                        "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "algorithmic_flop_per_propagation": flop,
-                        "avg_launch_ms": med / 2.0,
-                        "note": "HIP events around the two products of one propagation (main kernel + quarter-tile tail "
-                                "kernel on a second stream); median of the timed propagations"}}
+                        "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "avg_launch_ms": med / 2.0}}
     if want_cpu:
         try:
             from threadpoolctl import threadpool_limits
@@ -379,11 +405,9 @@ def leg_configs_3(device, cores, N=10003, iters=5, want_cpu=True):
                 prod()
             cdt = (time.perf_counter() - t0) / reps
         ctf = 4.0 * Nc ** 3 / cdt / 1e12
-        out["cpu_baseline"] = {"value": ctf * 1e12 / flop, "unit": "propagations/s (scaled from the sample by flop count)",
+        out["cpu_baseline"] = {"value": ctf * 1e12 / flop, "unit": "propagations/s (scaled by flop)",
                                "cores": cores, "kind": "port", "tflops": ctf,
-                               "sample": f"fp32 F Sigma F^T + Q at N={Nc} ({4.0 * Nc ** 3 / 1e9:.0f} GFLOP, {cdt:.2f} s) as two "
-                                         f"numpy/OpenBLAS sgemm calls on {cores} threads -- what Armadillo's operator* "
-                                         f"resolves to with a BLAS back end"}
+                               "sample": f"N={Nc}, {cdt:.2f} s, two OpenBLAS sgemm"}
     return out
 
 
@@ -413,7 +437,10 @@ def main():
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     red_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local)
-    if world > 1:
+    # Under the one-process-per-GPU launcher (RANK / MASTER_* in the environment) the process group is created even for a
+    # single rank: `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` then takes the very path an 8-rank job
+    # takes -- init_process_group("nccl", device_id=...), barriers and the scalar all-reduces through RCCL.
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -490,10 +517,16 @@ def main():
     cores = int(os.environ.get("EKF_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
     want_cpu = world == 1 and not a.no_cpu_baseline
     # the eager leg's own end states: the CPU baseline's parity spot-check and the other legs compare against THESE
+    # (a STRIDED sample over the whole pool -- first and last filter included -- so that no slab of the 132-GB covariance
+    # pool goes unchecked; round 3 took the first Bc filters)
     Bc = a.cpu_filters if a.cpu_filters > 0 else min(B, 160 * cores)
-    eager_state = None
+    cpu_ids = np.unique(np.linspace(0, B - 1, Bc).round().astype(np.int64))
+    Bc = len(cpu_ids)
+    eager_state = eager_first = None
     if rank == 0:
-        eager_state = np.stack([bt.state(b) for b in range(Bc if want_cpu else min(B, 4))])
+        eager_first = np.stack([bt.state(b) for b in range(min(B, 4))])   # what the other legs compare against
+        if want_cpu:
+            eager_state = np.stack([bt.state(int(b)) for b in cpu_ids])
 
     # Second, separately reported leg: the same log with the delayed
     # rank-2k covariance update.  Its traffic is different by construction, so it has its own declared
@@ -527,10 +560,7 @@ def main():
                        "declared_bytes_per_correction": per_corr,
                        "achieved_GBps_on_declared_bytes": dcorr / world * per_corr / dwall / 1e9,
                        "frac_of_8TBps": dcorr / world * per_corr / dwall / 1e9 / HBM_PEAK_GBS,
-                       "speedup_vs_eager": (dcorr / dwall) / (corr / wall),
-                       "note": "Sigma = Sigma_base - sum K_j (H Sigma)_j kept as factors, rewritten once per "
-                               "k corrections; the two corrections of a step share one gain launch; results equal the "
-                               "eager path to rounding (tests/test_gpu_delayed.py)"}
+                       "speedup_vs_eager": (dcorr / dwall) / (corr / wall)}
             # Parity of THIS configuration (n, k, pairs, automatic flush form) at the step it stands at, W + Kd: the first
             # filters of the pool (same global ids -> same inputs) re-run eagerly on a side pool, and on the CPU port.
             nref = min(B, 4)
@@ -588,13 +618,9 @@ def main():
             gcov = bt.cov(0)
             delayed["symmetric"] = {"value": gcorr / gwall, "unit": "update steps/s",
                                     "flush_avg_ms": sg["rank2_ms"] / max(sg["rank2_launches"], 1),
-                                    "flush_form": "mirrored (k_flush_sym)" if bt.form_counts()["flush_mirrored"] else "full",
+                                    "flush_form": "k_flush_sym" if bt.form_counts()["flush_mirrored"] else "full",
                                     "max_abs_state_diff_vs_eager": float(np.abs(gstate - rstate).max()),
-                                    "max_rel_cov_diff_vs_eager": float(np.abs(gcov - rcov).max() / np.abs(rcov).max()),
-                                    "note": "opt-in (ekf_set_update_mode's symmetric option): Sigma H^T is taken as (H Sigma)^T "
-                                            "and the flush forms the tiles on and above the diagonal only, mirroring them -- "
-                                            "not the reference's operands (it reads the column and never symmetrises); "
-                                            "reported beside the default, never as `value` of this leg"}
+                                    "max_rel_cov_diff_vs_eager": float(np.abs(gcov - rcov).max() / np.abs(rcov).max())}
         bt.set_update_mode(0)
 
     # Separately reported leg: the SAME steps with every measurement() call fused (ekf_callfused.hip) -- the gains and
@@ -629,10 +655,7 @@ def main():
                      "achieved_GBps_on_declared_bytes": ccorr / world * per_corr / cwall / 1e9,
                      "frac_of_8TBps": ccorr / world * per_corr / cwall / 1e9 / HBM_PEAK_GBS,
                      "speedup_vs_eager": (ccorr / cwall) / (corr / wall),
-                     "bit_identical_to_eager": bool(np.array_equal(cstate, eager_state[:len(cstate)])),
-                     "note": "exact: every element of Sigma takes the V = 2 rank-2 corrections of a call in order in one "
-                             "read-modify-write (tests/test_gpu_callfused.py); the eager per-correction stream above stays "
-                             "the contract path of `value` / `roofline`"}
+                     "bit_identical_to_eager": bool(np.array_equal(cstate, eager_first[:len(cstate)]))}
         bt.set_call_fused(False)
 
     # Third, separately reported leg: the eager correction restricted to the rows of the TOUCHED set (exact,
@@ -659,11 +682,7 @@ def main():
                       "declared_bytes_per_correction": 16.0 * N * (3 + 2 * float(tch.mean())),
                       "rank2_share_of_time": sa["rank2_ms"] / sa["elapsed_ms"],
                       "speedup_vs_eager": (acorr / awall) / (corr / wall),
-                      "bit_identical_to_eager": bool(np.array_equal(astate, eager_state[:len(astate)])),
-                      "note": "workload-dependent: rows of never-corrected landmarks have K = 0 exactly and are "
-                              "skipped (the 2 nearest landmarks of a slowly moving robot stay the same for many "
-                              "steps, so few are ever touched here); with every landmark corrected it degenerates "
-                              "to the dense stream"}
+                      "bit_identical_to_eager": bool(np.array_equal(astate, eager_first[:len(astate)]))}
         bt.set_active_set(False)
 
     out = None
@@ -675,25 +694,26 @@ def main():
         out = {
             "metric": "EKF update steps/sec + achieved HBM GB/s vs roofline, n=1000 landmarks",
             "value": corr / wall,
-            "unit": "update steps/s (1 update step = 1 landmark correction: gain + state + covariance)",
+            "unit": "update steps/s",
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall / K * 1e3,
-            "rank_ms_per_step_min": wall_min / K * 1e3, "rank_ms_per_step_max": wall_max / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[4], one GPU's share: {B} independent EKF_SLAM filters per "
-                                   f"GPU, n={n} landmarks (N={N}), known association, V=2 corrections per filter step",
+            "config": {"workload": f"BASELINE.json configs[4], one GPU's share: {B} filters, n={n}, known association, V=2",
                        "filters_per_gpu": B, "filters_total": int(round(fsteps / K)), "landmarks": n, "state_dim": N, "corrections_per_filter_step": 2,
-                       "filter_steps_per_s": fsteps / wall, "sharding": f"independent filters x {world} GPUs",
-                       "ranks_seen": ranks_seen, "hbm_bytes_per_gpu": bt.device_bytes()},
+                       "filter_steps_per_s": fsteps / wall,
+                       "ranks_seen": ranks_seen, "hbm_bytes_per_gpu": bt.device_bytes(),
+                       "collectives": (backend if dist is not None else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": f"{kname} (Sigma -= K*(H*Sigma), ekf_slam.cpp:191-192), {krows} rows per workgroup",
+                         "kernel": f"{kname}, {krows} rows/wg",
                          "algorithmic_bytes_per_launch": st["rank2_bytes_per_launch"],
                          "avg_launch_ms": r2_avg_s * 1e3, "launches": st["rank2_launches"],
                          "rank2_share_of_step_time": st["rank2_ms"] / st["elapsed_ms"]},
             "device_elapsed_ms": st["elapsed_ms"],
         }
+        if world > 1:
+            out["rank_ms_per_step_min"], out["rank_ms_per_step_max"] = wall_min / K * 1e3, wall_max / K * 1e3
         if traffic is None:
             out["roofline"]["traffic_note"] = why_not
         if delayed is not None:
@@ -713,11 +733,12 @@ def main():
             Tc = 1 + W + K
             if log is None:
                 tw, li, zz, ii, _ = bt.download_log(want_truth=False)
-                sub = synth.KnownLog(cfg_c, world_xy, tw[:Tc, :Bc], li[:Tc, :Bc], zz[:Tc, :Bc], ii[:Bc])
+                sub = synth.KnownLog(cfg_c, world_xy, tw[:Tc, cpu_ids], li[:Tc, cpu_ids], zz[:Tc, cpu_ids], ii[cpu_ids])
             else:
-                sub = synth.KnownLog(cfg_c, log.world, log.twist[:Tc, :Bc], log.lm_idx[:Tc, :Bc], log.z_xy[:Tc, :Bc],
-                                     log.init_xy[:Bc])
-            out["cpu_baseline"] = cpu_baseline(sub, K, 1 + W, cores, eager_state[:Bc])
+                sub = synth.KnownLog(cfg_c, log.world, log.twist[:Tc, cpu_ids], log.lm_idx[:Tc, cpu_ids],
+                                     log.z_xy[:Tc, cpu_ids], log.init_xy[cpu_ids])
+            out["cpu_baseline"] = cpu_baseline(sub, K, 1 + W, cores, eager_state)
+            out["cpu_baseline"]["filter_ids"] = [int(cpu_ids[0]), int(cpu_ids[-1]), int(len(cpu_ids))]   # first, last, count
 
     # Separately reported leg: data_association() (a4/a5) over the same pool -- every robot discovers its map
     # from shuffled, unlabelled readings generated on the device; scores, gate decisions, landmark initialisation
@@ -741,17 +762,12 @@ def main():
         if rank == 0:
             kc = bt.known_counts()
             out["unknown_association"] = {
-                "value": usteps / uwall, "unit": "filter steps/s (1 step = prediction + data_association of <= 8 readings)",
+                "value": usteps / uwall, "unit": "filter steps/s",
                 "corrections_per_s": ucorr / uwall, "measurement_slots": su["rank2_launches"],
                 "known_landmarks_min": int(kc.min()), "known_landmarks_max": int(kc.max()),
                 "active_dimension_max": 3 + 2 * int(kc.max()),
                 "rank2_share_of_time": su["rank2_ms"] / su["elapsed_ms"],
-                "mc_consistency": bt.mc_stats(Tu - 1),
-                "note": f"capacity n = {n}, but after {Tu} steps each filter has discovered only "
-                        f"{int(kc.min())}..{int(kc.max())} landmarks: this leg measures the SMALL discovered-prefix regime "
-                        "(LDS-resident step kernel); landmarks are appended in discovery order, so each filter's "
-                        "corrections stream only its leading 3 + 2*known block (bit-identical to the full-width update, "
-                        "tests/test_gpu_batch_unknown.py).  The large-prefix regime is `unknown_association_large_prefix`"}
+                "mc_consistency": bt.mc_stats(Tu - 1)}
     # The LARGE-prefix regime of the same path: every robot explores a map it has already surveyed (phase A, untimed:
     # a host-written known-association log corrects each of the n landmarks once from the origin), then runs unknown
     # association against all n of them -- every reading is scored against 1000 landmarks (one per wavefront,
@@ -796,7 +812,7 @@ def main():
             nmeas = int((dec > -2).sum()) * world
             r2_s = sl["rank2_ms"] / max(sl["rank2_launches"], 1) * 1e-3
             out["unknown_association_large_prefix"] = {
-                "value": lsteps / lwall, "unit": "filter steps/s (1 step = prediction + data_association of <= 8 readings)",
+                "value": lsteps / lwall, "unit": "filter steps/s",
                 "measurements_per_s": nmeas / lwall, "scores_per_s": nmeas * float(n) / lwall,
                 "corrections_per_s": lcorr / lwall, "filters_per_gpu": Bl,
                 "known_landmarks_min": int(kc.min()), "known_landmarks_max": int(kc.max()),
@@ -805,13 +821,7 @@ def main():
                 "covariance_GBps": Bl * 16.0 * N * N / r2_s / 1e9,
                 "frac_of_8TBps_in_the_pass": Bl * 16.0 * N * N / r2_s / 1e9 / HBM_PEAK_GBS,
                 "frac_of_8TBps_end_to_end": lsteps / lwall * 16.0 * N * N / 1e9 / HBM_PEAK_GBS,
-                "mc_consistency": dict(lb.mc_stats(Tu - 1), step=Tu - 1),
-                "note": "known_count = n for every filter (map surveyed through the known-association path first): the "
-                        "discovered prefix is the whole state.  Two launches per step: a workgroup per filter scores every "
-                        "reading against all n landmarks, decides and builds the gains against the stored covariance minus "
-                        "the step's pending pairs (ekf_stepfused.hip); one pass of ekf::k_rank2v (K values staged in LDS) then "
-                        "streams every 32-MB covariance ONCE per step (covariance_GBps = filters x 16 N^2 B per pass); "
-                        "bit-identical to four launches per measurement slot"}
+                "mc_consistency": dict(lb.mc_stats(Tu - 1), step=Tu - 1)}
         # The same leg in DELAYED mode (ekf_batch_set_update_mode): the pairs of a step stay pending across steps, every
         # reading is scored and corrected against the stored covariance minus all pending pairs, Sigma is rewritten once per
         # kdl / J steps.  Timed over the steps that follow the eager leg's; parity against an eager side pool of the first
@@ -848,10 +858,7 @@ def main():
                 "parity_filters": nref, "decisions_identical_to_eager": bool(np.array_equal(dec_d, dec_e)),
                 "max_abs_state_diff_vs_eager": sdiff,
                 "max_rel_cov_diff_vs_eager": float(np.abs(c_d - c_e).max() / np.abs(c_e).max()),
-                "mc_consistency": dict(lb.mc_stats(Tu + Kdl - 1), step=Tu + Kdl - 1),
-                "note": "pools' data_association() in delayed mode: jmax = 8 pairs per step and filter stay pending across "
-                        "steps (ekf_stepfused.hip, DELAYED), one flush per 4 steps instead of one pass per step; "
-                        "tests/test_gpu_batch_unknown.py::test_delayed_data_association_for_pools"}
+                "mc_consistency": dict(lb.mc_stats(Tu + Kdl - 1), step=Tu + Kdl - 1)}
         # ... and with the opt-in symmetric option (row-only reconstruction in the step kernel, mirrored flush), over the
         # steps that follow; same side pool
         lb.set_update_mode(kdl, symmetric_gather=True)
@@ -868,11 +875,10 @@ def main():
             out["unknown_association_large_prefix"]["delayed"]["symmetric"] = {
                 "value": dsteps3 / dwall3, "unit": "filter steps/s", "steps": Kdl,
                 "flush_avg_ms": sd3["rank2_ms"] / max(sd3["rank2_launches"], 1),
-                "flush_form": "mirrored (k_flush_sym)" if lb.form_counts()["flush_mirrored"] else "full",
+                "flush_form": "k_flush_sym" if lb.form_counts()["flush_mirrored"] else "full",
                 "decisions_identical_to_eager": bool(np.array_equal(lb.decisions()[:, :nref], ref.decisions())),
                 "max_abs_state_diff_vs_eager": max(float(np.abs(lb.state(b) - ref.state(b)).max()) for b in range(nref)),
-                "max_rel_cov_diff_vs_eager": float(np.abs(c_d - c_e).max() / np.abs(c_e).max()),
-                "note": "opt-in symmetric option of ekf_set_update_mode; reported beside the default"}
+                "max_rel_cov_diff_vs_eager": float(np.abs(c_d - c_e).max() / np.abs(c_e).max())}
             ref.close()
         lb.close()
     # The reference's own operating point at Monte-Carlo scale: configs[0] (n = 20, 1000 steps) for 8192 robots per
@@ -895,11 +901,9 @@ def main():
                                                        device=red_dev)
         if rank == 0:
             out["small_map_monte_carlo"] = {
-                "value": ssteps / swall, "unit": "filter steps/s (1 step = prediction + measurement of the visible landmarks)",
+                "value": ssteps / swall, "unit": "filter steps/s",
                 "corrections_per_s": scorr / swall, "filters_per_gpu": Bs, "landmarks": ns, "steps": Ts - 1,
-                "launches": ss["rank2_launches"], "mc_consistency": sb.mc_stats(Ts - 1),
-                "note": "BASELINE.json configs[0] (the reference's n = 20 known-association run) for every filter; "
-                        "bit-identical to the per-step replay (tests/test_gpu_pool_small.py)"}
+                "launches": ss["rank2_launches"], "mc_consistency": sb.mc_stats(Ts - 1)}
         sb.close()
     bt.close()
     # The other BASELINE.json configurations (N = 1 only: they are single-GPU, single-filter workloads).
@@ -911,7 +915,10 @@ def main():
             except Exception as e:  # a failing side leg must not take the contract line down with it
                 out[key] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        line = json.dumps(compact(out), separators=(",", ":"))
+        # the driver keeps an 8 KB tail of the run's output: every leg must be readable there (README: what each key means)
+        assert len(line) < LINE_BUDGET, f"bench line is {len(line)} characters, budget {LINE_BUDGET}"
+        print(line, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

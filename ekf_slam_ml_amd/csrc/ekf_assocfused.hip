@@ -265,11 +265,11 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc_reading(
             pv.rec[0] = rc;
             if (active) touch_landmark(pv, 0, idx);
             if (pub_host) {   // the host's copy (see k_assoc_call): behind the call's last decision the record and the number
-                reinterpret_cast<int*>(pub_host + 64)[pub_j] = a.lm;
+                reinterpret_cast<int*>(pub_host + kAssocDecOff)[pub_j] = a.lm;
                 if (pub_seq) {
                     *reinterpret_cast<AssocRec*>(pub_host) = a;
                     __threadfence_system();
-                    *reinterpret_cast<volatile unsigned*>(pub_host + 32) = pub_seq;
+                    *reinterpret_cast<volatile unsigned*>(pub_host + kAssocSeqOff) = pub_seq;
                 }
             }
         }
@@ -578,13 +578,13 @@ __global__ __launch_bounds__(THREADS) void k_assoc_call(PoolView pv, AssocCallAr
             // The host's copy (mapped memory, see k_publish_assoc): the decision now, and behind the call's LAST decision the
             // record and the sequence number -- the host goes on while this launch builds the last gain.
             if (pub_host) {
-                reinterpret_cast<int*>(pub_host + 64)[pub_j0 + j] = active ? idx : -1;
+                reinterpret_cast<int*>(pub_host + kAssocDecOff)[pub_j0 + j] = active ? idx : -1;
                 if (pub_seq && j == a.J - 1) {
                     AssocRec rec;
                     rec.known_count = Mn; rec.lm = active ? idx : -1; rec.active = active; rec.pad = 0; rec.best = 0.0;
                     *reinterpret_cast<AssocRec*>(pub_host) = rec;
                     __threadfence_system();
-                    *reinterpret_cast<volatile unsigned*>(pub_host + 32) = pub_seq;
+                    *reinterpret_cast<volatile unsigned*>(pub_host + kAssocSeqOff) = pub_seq;
                 }
             }
         }
@@ -592,7 +592,13 @@ __global__ __launch_bounds__(THREADS) void k_assoc_call(PoolView pv, AssocCallAr
         AC_TR(j, 3);
         const int lm = sh_lm;
         const int is_new = sh_new;
-        if (lm < 0) { __syncthreads(); continue; }   // dropped (uniform); the barrier keeps sh_lm stable for slow waves
+        if (lm < 0) {   // dropped (uniform); the barrier keeps sh_lm stable for slow waves
+            // a landmark that was initialised and then dropped (gate_update <= 0: 0.0 < gate is false) keeps the position
+            // of :321-322 all the same -- its thread takes it now, the correction below never runs
+            if (is_new && has_lm && t == sh_M - 1) { pos[0] = sh_t[0]; pos[1] = sh_t[1]; }
+            __syncthreads();
+            continue;
+        }
         // ---- requests: Sigma(r, c5(lm)) and Sigma(c5(lm), r) for the owned indices; the pairs' values at the winner ----
         // the active dimension of this reading (landmarks are appended in discovery order, :318-327): K, G are exact zeros beyond
         int mact = a.known_count + j + 1 < n ? a.known_count + j + 1 : n;

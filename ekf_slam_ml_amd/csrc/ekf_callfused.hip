@@ -375,16 +375,25 @@ __global__ __launch_bounds__(kCtl + SLICE) void k_call_factors(PoolView pv, Call
     // wave execute in order) and a waiting wave polls; every spin is bounded.  Only barrier A, which the slices need too,
     // stays a workgroup barrier -- the slices pass ONE barrier per correction instead of two, and wave 0 no longer
     // waits for the angle wave before S, S^-1 and K (it needs nu1 only for the last ten instructions of a correction).
+    // Memory order: the counter is published with a workgroup-scope RELEASE store and read with a workgroup-scope ACQUIRE
+    // load -- what the memory model asks for, not the in-order execution of DS instructions (the compiler waits for the
+    // wave's LDS writes in front of the store; that s_waitcnt was there already).
     auto publish = [&](int which, int value) {
-        wave_sync_lds();
-        if (lane == 0) __hip_atomic_store(&sh_done[which], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(&sh_done[which], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+    // All waves of a workgroup are resident together, so the counter arrives unless a wave has died.  The spin is bounded
+    // all the same; when the bound is hit the wave does NOT go on as if its operands were there: it raises the pool's
+    // device error word (the host fails every later call of the handle with EKF_ERR_HIP) and only then leaves the loop, so
+    // that the workgroup still reaches its barriers and the grid drains.
     auto await = [&](int which, int value) {
+        bool arrived = false;
         for (int spin = 0; spin < (1 << 22); spin++) {
-            if (__hip_atomic_load(&sh_done[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= value) break;
+            if (__hip_atomic_load(&sh_done[which], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= value) { arrived = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
-        wave_sync_lds();
+        if (!arrived && lane == 0) report_device_error(pv, kErrHandoffTimeout);
+        __builtin_amdgcn_wave_barrier();
     };
     // G_v = H_v Sigma[c5(v), :] on the core columns: needs H and the updated block, not S^-1 -- wave 2, beside wave 0
     auto core_G = [&](int v) {

@@ -209,15 +209,17 @@ static ekf_status associate_finish(Pool& P, int known_count, int J, uint8_t* kno
     if (P.pub_host) {   // record and decisions through mapped host memory: the host waits for the sequence number only
         EKFC(P.publish_assoc(J));   // (callers with a covariance pass behind the last decision have published in front of it)
         P.pub_sent = false;
-        volatile unsigned* seq = reinterpret_cast<volatile unsigned*>(P.pub_host + 32);
+        volatile unsigned* seq = reinterpret_cast<volatile unsigned*>(P.pub_host + Pool::kAssocSeqOff);
         for (unsigned spins = 1; *seq != P.pub_seq; spins++) {
-            if ((spins & 0xFFFF) == 0 && hipStreamQuery(P.stream) != hipErrorNotReady) {
+            __builtin_ia32_pause();   // (a polite spin: the sibling hyperthread keeps its issue slots; a call is microseconds)
+            if ((spins & 0x3FFF) == 0 && hipStreamQuery(P.stream) != hipErrorNotReady) {
                 // the stream has drained (or failed): the number must be there now, or never will be
                 HIPC(hipStreamSynchronize(P.stream));
                 if (*seq != P.pub_seq) return fail(EKF_ERR_HIP, "data_association: the result was not published");
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
+        EKFC(P.check_device());
         std::memcpy(&rec, P.pub_host, sizeof(rec));
         if (assoc_out) std::memcpy(assoc_out, P.pub_host + Pool::kAssocDecOff, sizeof(int) * (size_t)J);
     } else if (P.assoc_block) {   // records and decisions in one block: one copy, one synchronisation

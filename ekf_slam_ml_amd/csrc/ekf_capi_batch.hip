@@ -398,6 +398,10 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
             ekf::launch_predict(pvp, P.ulog_twist + (size_t)t * B * 2, 0.0, 0.0, P.pending(), P.stream,
                                 delayed ? P.cf_pred : nullptr);
         }
+        // A delayed step in which NO filter has a reading launches no step kernel, so nothing would carry this step's
+        // prediction into the block cache (the kernel applies its own step's At / Q to the cached 5 x 5 blocks): fold the
+        // pending pairs now -- the next step with readings then rebuilds every block from Sigma (ekf_slam.cpp:55-106,300-309).
+        if (delayed && smax == 0) EKFC(timed_flush());
         if (want_small && smax > 0 && Nstep <= ekf::small_max_dim()) {
             if (delayed) EKFC(timed_flush());   // (the LDS-resident step works on the materialised covariance)
             pva.N = Nstep;

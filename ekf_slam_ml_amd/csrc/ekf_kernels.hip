@@ -850,12 +850,12 @@ __global__ void k_gather_poses(PoolView pv, double* out) {
 // host memory + a host spin on a flag word 6.8 us): record and decisions first, system-scope fence, then the sequence number.
 __global__ __launch_bounds__(64) void k_publish_assoc(const AssocRec* __restrict__ rec, const int* __restrict__ decisions, int J,
                                                       char* host, unsigned seq) {
-    int* hd = reinterpret_cast<int*>(host + 64);
+    int* hd = reinterpret_cast<int*>(host + kAssocDecOff);
     for (int j = threadIdx.x; j < J; j += 64) hd[j] = decisions[j];
     if (threadIdx.x == 0) *reinterpret_cast<AssocRec*>(host) = rec[0];
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(host + 32) = seq;
+    if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(host + kAssocSeqOff) = seq;
 }
 
 void launch_publish_assoc(const AssocRec* rec, const int* decisions, int J, char* host, unsigned seq, hipStream_t s) {

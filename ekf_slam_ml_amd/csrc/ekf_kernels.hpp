@@ -125,7 +125,20 @@ struct PoolView {
     int n, N, ld, B;
     size_t sigma_stride;  // doubles between consecutive filters' covariances = N * ld
     Params p;
+    // Device error word in mapped host memory (one per pool; never null once the pool exists): a kernel that cannot go on
+    // -- an in-kernel hand-off that never arrives -- sets a bit here instead of continuing with stale operands; the host
+    // runtime turns a non-zero word into EKF_ERR_HIP at its next entry or synchronisation point (Pool::check_device).
+    unsigned* err;
 };
+enum : unsigned { kErrHandoffTimeout = 1u };
+__device__ __forceinline__ void report_device_error(const PoolView& pv, unsigned bit) {
+    __hip_atomic_fetch_or(pv.err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Layout of a single filter's association block -- [record | record | decisions] on the device, and its mirror in mapped
+// host memory [record | sequence number | decisions] that the deciding kernels publish to (ekf_runtime.hpp, Pool).
+constexpr size_t kAssocRecSlot = 32, kAssocSeqOff = 32, kAssocDecOff = 64;
+static_assert(sizeof(AssocRec) <= kAssocRecSlot, "AssocRec must fit its slot: the sequence number sits right behind it");
 
 // called by ONE lane per filter and correction
 __device__ __forceinline__ void touch_landmark(const PoolView& pv, int b, int lm) {

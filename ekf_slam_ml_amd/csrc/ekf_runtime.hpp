@@ -407,8 +407,18 @@ struct Pool {
         if (active_prefix && pend_cap == 0 && touched_hwm < pv.n) view.N = 3 + 2 * touched_hwm;
         ekf::launch_predict(view, nullptr, dth, dx, pending(), stream);
     }
+    // Device error word (PoolView::err): sticky.  A kernel that gave up (a bounded in-kernel hand-off that never arrived)
+    // has left results nobody may use: every later entry point of the handle fails with EKF_ERR_HIP.
+    unsigned* err_host = nullptr;
+    ekf_status check_device() const {
+        if (err_host && *reinterpret_cast<volatile unsigned*>(err_host) != 0u)
+            return fail(EKF_ERR_HIP, "a kernel reported a device-side error (word " + std::to_string(*err_host) +
+                                         ": an in-kernel hand-off timed out); the handle's results are invalid");
+        return EKF_OK;
+    }
     ekf_status use(bool settle = true) {
         HIPC(hipSetDevice(device));
+        EKFC(check_device());
         if (settle && pred_pending) {
             pred_pending = false;
             launch_predict_now(pred_dth, pred_dx);
@@ -462,6 +472,9 @@ struct Pool {
         EKFC(dalloc(&poses_dev, (size_t)B * 3));
         HIPC(hipEventCreate(&ev_begin));
         HIPC(hipEventCreate(&ev_end));
+        HIPC(hipHostMalloc((void**)&err_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *err_host = 0u;
+        pv.err = err_host;   // (unified addressing: the mapped pointer is valid on the device)
         return reset();
     }
 
@@ -495,6 +508,8 @@ struct Pool {
         stage_out.release();
         if (pub_host) (void)hipHostFree(pub_host);
         pub_host = nullptr;
+        if (err_host) (void)hipHostFree(err_host);
+        err_host = nullptr;
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -506,7 +521,7 @@ struct Pool {
     ekf_status sync() {
         EKFC(use());
         HIPC(hipStreamSynchronize(stream));
-        return EKF_OK;
+        return check_device();
     }
 
     // host -> device through the pinned staging buffer, ordered on the stream
@@ -530,6 +545,7 @@ struct Pool {
         EKFC(stage_out.reserve(bytes));
         HIPC(hipMemcpyAsync(stage_out.host, src, bytes, hipMemcpyDeviceToHost, stream));
         HIPC(hipStreamSynchronize(stream));
+        EKFC(check_device());
         std::memcpy(dst, stage_out.host, bytes);
         return EKF_OK;
     }
@@ -542,6 +558,7 @@ struct Pool {
         HIPC(hipMemcpyAsync(hostp, src1, bytes1, hipMemcpyDeviceToHost, stream));
         if (bytes2) HIPC(hipMemcpyAsync(hostp + off2, src2, bytes2, hipMemcpyDeviceToHost, stream));
         HIPC(hipStreamSynchronize(stream));
+        EKFC(check_device());
         std::memcpy(dst1, hostp, bytes1);
         if (bytes2) std::memcpy(dst2, hostp + off2, bytes2);
         return EKF_OK;
@@ -568,6 +585,7 @@ struct Pool {
         HIPC(hipMemcpy2DAsync(stage_out.host, w, pv.sigma + (size_t)b * pv.sigma_stride, sizeof(double) * pv.ld, w,
                               pv.N, hipMemcpyDeviceToHost, stream));
         HIPC(hipStreamSynchronize(stream));
+        EKFC(check_device());
         std::memcpy(out, stage_out.host, w * pv.N);
         return EKF_OK;
     }
@@ -594,7 +612,7 @@ struct Pool {
     // Single filter: the two association records (they ping-pong between launches) and the decisions of a call live in
     // ONE block -- [record | record | decisions] -- so that data_association() ends with one device-to-host copy.
     char* assoc_block = nullptr;
-    static constexpr size_t kAssocRecSlot = 32, kAssocDecOff = 64;
+    static constexpr size_t kAssocRecSlot = ekf::kAssocRecSlot, kAssocSeqOff = ekf::kAssocSeqOff, kAssocDecOff = ekf::kAssocDecOff;
     // ... and its mirror in mapped host memory ([record | sequence number | decisions]): k_publish_assoc writes it, the
     // host spins on the sequence number -- no copy engine, no stream synchronisation at the end of a call
     char* pub_host = nullptr;
@@ -631,7 +649,8 @@ struct Pool {
             assoc_block = blk;
             if (pub_host) HIPC(hipHostFree(pub_host));
             pub_host = nullptr;
-            HIPC(hipHostMalloc((void**)&pub_host, kAssocDecOff + sizeof(int) * (size_t)cap, hipHostMallocMapped));
+            HIPC(hipHostMalloc((void**)&pub_host, kAssocDecOff + sizeof(int) * (size_t)cap,
+                               hipHostMallocMapped | hipHostMallocCoherent));   // (the host spins on it: fine-grained)
             std::memset(pub_host, 0, kAssocDecOff);
             pv.assoc = reinterpret_cast<ekf::AssocRec*>(blk);
             assoc_alt = reinterpret_cast<ekf::AssocRec*>(blk + kAssocRecSlot);

@@ -79,7 +79,16 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
  *                                                   ekf_slam.hpp:41, ekf_slam.cpp:278-402.
  * meas_xy: 2J doubles (Vector2D is {double x, y}, rigid2d.hpp:68-72, so &measures[0].x);
  * known: n bytes, IN/OUT (entries are set as landmarks are initialised, :323);
- * assoc_out: optional J ints, the landmark each measurement updated (-1 = dropped). */
+ * assoc_out: optional J ints, the landmark each measurement updated (-1 = dropped).
+ * Synchronous in its RESULTS only: the call returns when the decisions and known_list are final; the gain of the last
+ * reading and the call's pass over the covariance may still be running on the handle's stream.  An execution error of
+ * that tail (or a device-side error word, EKF_ERR_HIP) therefore surfaces at the NEXT call that synchronises with the
+ * stream (ekf_sync, any getter, the next ekf_associate); stream order keeps every later call behind it.
+ * Which launch structure ("form") runs is chosen by map size; state, covariance, decisions and known_list are
+ * bit-identical across forms.  Internal bookkeeping is not: the diagnostic winning distance of the association record
+ * is only kept by the per-reading forms, and the touched set (ekf_set_active_set) is "every landmark below the known
+ * count" on the call-fused forms and "landmarks actually corrected" on the others -- both supersets of what the
+ * exact sparsity needs. */
 ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* known, int* assoc_out);
 
 /* double calculate_maha_dis(Vector2D, int) for i in [0, M)   ekf_slam.hpp:86, ekf_slam.cpp:217-276.

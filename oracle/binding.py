@@ -36,6 +36,10 @@ def _cpu_has(*flags):
 def _load(fast=False):
     build()
     name = "libekf_oracle_fast.so" if (fast and _cpu_has("avx2", "fma")) else "libekf_oracle.so"
+    # EKF_ORACLE_SANITIZED=1 (tests/test_sanitizers.py, `make -C oracle asan`): the same sources built with
+    # -fsanitize=address,undefined; the process must have been started with libasan preloaded
+    if os.environ.get("EKF_ORACLE_SANITIZED") == "1":
+        name = "libekf_oracle_asan.so"
     lib = C.CDLL(os.path.join(_HERE, name))
     lib.ekfo_create.restype = C.c_void_p
     lib.ekfo_create.argtypes = [C.c_int, C.c_int, C.c_void_p]
@@ -52,6 +56,8 @@ def _load(fast=False):
     lib.ekfo_maha.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
     lib.ekfo_data_association.restype = C.c_int
     lib.ekfo_data_association.argtypes = [C.c_void_p, _dp, C.c_int, _bp, _ip]
+    lib.ekfo_data_association_m.restype = C.c_int
+    lib.ekfo_data_association_m.argtypes = [C.c_void_p, _dp, C.c_int, _bp, _ip, _dp]
     for f in ("ekfo_get_state", "ekfo_set_state", "ekfo_get_cov", "ekfo_set_cov"):
         getattr(lib, f).argtypes = [C.c_void_p, _dp]
     lib.ekfo_set_init_flag.argtypes = [C.c_void_p, C.c_int]
@@ -82,6 +88,11 @@ def _d(a):
 
 
 DENSE, STRUCTURED = 0, 1
+MARGIN_KEYS = ("to_gate_new", "to_gate_update", "winner_to_runner_up", "smallest_score")
+
+
+def new_margins():
+    return np.full(4, np.inf)
 
 
 class OracleEKF:
@@ -119,11 +130,18 @@ class OracleEKF:
     def maha(self, mx, my, i):
         return self._lib.ekfo_maha(self._h, float(mx), float(my), int(i))
 
-    def data_association(self, meas_xy, known):
-        """known: uint8[n] numpy array, modified in place; returns per-measurement landmark (-1 dropped)."""
+    def data_association(self, meas_xy, known, margins=None):
+        """known: uint8[n] numpy array, modified in place; returns per-measurement landmark (-1 dropped).
+        margins: optional float64[4] (new_margins()), MIN-accumulated over calls: relative distance of every score to
+        gate_new / gate_update, winner-to-runner-up gap, smallest score (ekf_oracle.c, ekfo_data_association_m)."""
         m = np.ascontiguousarray(meas_xy, dtype=np.float64).reshape(-1, 2)
         assert known.dtype == np.uint8 and known.size == self.n and known.flags.c_contiguous
         assoc = np.full(len(m), -1, dtype=np.int32)
+        if margins is not None:
+            assert margins.dtype == np.float64 and margins.size == 4 and margins.flags.c_contiguous
+            self._lib.ekfo_data_association_m(self._h, _d(m), len(m), known.ctypes.data_as(_bp),
+                                              assoc.ctypes.data_as(_ip), _d(margins))
+            return assoc
         self._lib.ekfo_data_association(self._h, _d(m), len(m), known.ctypes.data_as(_bp),
                                         assoc.ctypes.data_as(_ip))
         return assoc

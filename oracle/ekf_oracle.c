@@ -432,8 +432,18 @@ double ekfo_maha(ekfo *o, double sx, double sy, int i) {
 
 /* rigid2d/src/ekf_slam.cpp:278-402.  known is in/out (:323).  Returns the
  * number of corrections applied; assoc_out (J ints, nullable) records the
- * landmark each measurement was matched to (-1 = dropped). */
-int ekfo_data_association(ekfo *o, const double *meas_xy, int J, unsigned char *known, int *assoc_out) {
+ * landmark each measurement was matched to (-1 = dropped).
+ *
+ * margins (nullable, 4 doubles, MIN-accumulated: the caller starts them at
+ * +inf) records how far the discrete decisions of :293-330 sit from flipping --
+ * the only place where another summation order (real Armadillo / BLAS against
+ * this restatement) could change a result by more than rounding:
+ *   [0] min over every scored (reading, landmark) pair of |d - gate_new| / gate_new       (:293,305)
+ *   [1] min over every scored pair of |d - gate_update| / gate_update                     (:330)
+ *   [2] min over readings with a winner of (runner_up - winner) / runner_up               (:305-309)
+ *   [3] min over every scored pair of d itself (a score is a positive-definite form)      */
+int ekfo_data_association_m(ekfo *o, const double *meas_xy, int J, unsigned char *known, int *assoc_out,
+                            double *margins) {
     int known_count = 0;
     for (int i = 0; i < o->n; i++) {          /* :281-288 leading run of true */
         if (known[i]) known_count++; else break;
@@ -443,9 +453,21 @@ int ekfo_data_association(ekfo *o, const double *meas_xy, int J, unsigned char *
         double mx = meas_xy[2 * j], my = meas_xy[2 * j + 1];
         double min_maha_dis = o->p.gate_new;  /* :293 */
         int min_maha_idx = known_count;       /* :294 */
+        double first = INFINITY, second = INFINITY;   /* (margins only) the two smallest scores of this reading */
         for (int i = 0; i < known_count; i++) {
             double d = ekfo_maha(o, mx, my, i);
             if (d < min_maha_dis) { min_maha_dis = d; min_maha_idx = i; }
+            if (margins && d == d) {
+                double a = fabs(d - o->p.gate_new) / o->p.gate_new, b = fabs(d - o->p.gate_update) / o->p.gate_update;
+                if (a < margins[0]) margins[0] = a;
+                if (b < margins[1]) margins[1] = b;
+                if (d < margins[3]) margins[3] = d;
+                if (d < first) { second = first; first = d; } else if (d < second) second = d;
+            }
+        }
+        if (margins && min_maha_idx < known_count && second < INFINITY) {
+            double g = (second - first) / second;
+            if (g < margins[2]) margins[2] = g;
         }
         if (min_maha_idx == known_count && min_maha_idx < o->n) { /* :318-327 */
             initialize_landmark(o, mx, my, min_maha_idx);
@@ -461,6 +483,10 @@ int ekfo_data_association(ekfo *o, const double *meas_xy, int J, unsigned char *
         }
     }
     return done;
+}
+
+int ekfo_data_association(ekfo *o, const double *meas_xy, int J, unsigned char *known, int *assoc_out) {
+    return ekfo_data_association_m(o, meas_xy, J, known, assoc_out, NULL);
 }
 
 static double now_s(void) {

@@ -21,6 +21,10 @@ from oracle.np_restatement import NumpyEKF  # noqa: E402
 from parity import worst  # noqa: E402
 
 AGREE = 1e-12
+# Decision margins ("fixtures need margins"): the oracle is unpinned, so a fixture whose scores sit
+# closer than this (relative) to the gates 10.0 / 1.0 of ekf_slam.cpp:293,330, or whose winner beats the runner-up by
+# less (ekf_slam.cpp:305-309), is not written -- another summation order could flip it.  Pick another seed instead.
+MIN_MARGIN = 1e-6
 
 
 def agree(o, p, what):
@@ -54,19 +58,21 @@ def unknown(name, cfg):
     o, p = ob.OracleEKF(n, ob.DENSE), NumpyEKF(n)
     ko, kp = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
     assoc = np.full((T, log.meas_xy.shape[2]), -2, dtype=np.int32)
+    margins = ob.new_margins()
     for t in range(T):
         J = int(log.count[t, 0])
         m = log.meas_xy[t, 0, :J]
         o.prediction(*log.twist[t, 0]); p.prediction(*log.twist[t, 0])
-        a = o.data_association(m, ko)
+        a = o.data_association(m, ko, margins)
         b = p.data_association(m, kp)
         assert np.array_equal(a, b) and np.array_equal(ko, kp), f"{name}: decisions differ at step {t}"
         assoc[t, :J] = a
     w = agree(o, p, name)
+    assert margins[:3].min() >= MIN_MARGIN, f"{name}: decision margins too thin {dict(zip(ob.MARGIN_KEYS, margins))}"
     np.savez_compressed(os.path.join(HERE, name + ".npz"), n=n, twist=log.twist[:, 0], count=log.count[:, 0],
-                        meas_xy=log.meas_xy[:, 0], assoc=assoc, known=ko, state=o.state, cov=o.cov)
+                        meas_xy=log.meas_xy[:, 0], assoc=assoc, known=ko, state=o.state, cov=o.cov, margins=margins)
     print(f"{name}: n={n} T={T} known={int(ko.sum())} updates={(assoc >= 0).sum()} dropped={(assoc == -1).sum()} "
-          f"C-vs-NumPy {w:.2e}")
+          f"C-vs-NumPy {w:.2e} margins {dict(zip(ob.MARGIN_KEYS, margins))}")
 
 
 def maha(name):
@@ -87,10 +93,15 @@ def maha(name):
 
 if __name__ == "__main__":
     ob.build()
-    known("known_n20", synth.config1(steps=250), {0, 1, 10, 100, 249})
-    c = synth.config1(steps=200)
-    c.seed = 77
-    unknown("unknown_n20", c)
-    c2 = synth.config2(steps=12)
-    known("known_n200", c2, {0, 5, 11})
-    maha("maha_n20")
+    only = set(sys.argv[1:])   # e.g. `make_golden.py unknown_n20`: rewrite that fixture alone
+    if not only or "known_n20" in only:
+        known("known_n20", synth.config1(steps=250), {0, 1, 10, 100, 249})
+    if not only or "unknown_n20" in only:
+        c = synth.config1(steps=200)
+        c.seed = 77
+        unknown("unknown_n20", c)
+    if not only or "known_n200" in only:
+        c2 = synth.config2(steps=12)
+        known("known_n200", c2, {0, 5, 11})
+    if not only or "maha_n20" in only:
+        maha("maha_n20")

@@ -489,3 +489,39 @@ def test_delayed_data_association_with_the_symmetric_option(hip):
         assert np.abs(snap[0][2][b] - snap[1][2][b]).max() < 1e-9
     assert_parity(snap[1][2][B - 1], snap[1][3], snap[0][2][B - 1], snap[0][3], FP64_TOL, "symmetric delayed vs eager")
 
+
+
+@pytest.mark.parametrize("k,silent", [(32, (2,)), (64, (1, 2)), (64, (3, 6)), (32, (0,))])
+def test_delayed_data_association_with_a_step_nobody_reads(hip, k, silent):
+    """A delayed step in which NO filter of the pool has a reading (count[t, :] = 0) between two flushes: the step still
+    predicts (ekf_slam.cpp:55-106), so the pending pairs and the cached 5 x 5 blocks must take At . At^T + Q before the next
+    reading is scored (ekf_slam.cpp:300-309).  Decisions, known counts identical to the eager run, states and covariances
+    within 1e-9 of it (round 3's advisor finding: the pool-wide silent step left the block cache one prediction behind)."""
+    n, B, T = 150, 10, 10
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=991, half_extent=5.0, min_spacing=0.3, max_visible_dis=1.4, vmax=8,
+                          v_cmd=1.0, w_cmd=0.6)
+    log = synth.make_unknown_log(cfg)
+    cnt = log.count.copy()
+    for t in silent:
+        cnt[t, :] = 0
+    rng = np.random.default_rng(7)
+    init = (log.world[None] + rng.normal(0.0, 0.005, size=(B, n, 2))).reshape(B, 2 * n)
+    lm0 = np.full((2, B, 1), -1, dtype=np.int32)
+    snap = []
+    for mode in (0, k):
+        bt = hip.BatchEKF(B, n)
+        bt.upload_known_log(np.zeros((2, B, 2)), lm0, np.zeros((2, B, 1, 2)), init)
+        bt.run_known()
+        bt.set_known_counts(np.full(B, n, dtype=np.int32))
+        bt.set_update_mode(mode)
+        bt.upload_unknown_log(log.twist, cnt, log.meas_xy)
+        bt.run_unknown(0, T)
+        snap.append((bt.decisions().copy(), bt.known_counts().copy(), [bt.state(b) for b in range(B)],
+                     [bt.cov(b) for b in (0, B - 1)]))
+        bt.close()
+    assert (snap[0][0] >= 0).sum() > 200                      # the run corrects
+    assert np.array_equal(snap[0][0], snap[1][0]) and np.array_equal(snap[0][1], snap[1][1])
+    for b in range(B):
+        assert np.abs(snap[0][2][b] - snap[1][2][b]).max() < 1e-9, f"filter {b}"
+    for i, b in enumerate((0, B - 1)):
+        assert_parity(snap[1][2][b], snap[1][3][i], snap[0][2][b], snap[0][3][i], FP64_TOL, f"delayed vs eager, filter {b}")

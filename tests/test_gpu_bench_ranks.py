@@ -53,10 +53,10 @@ def test_two_ranks_through_torchrun_aggregate_like_one():
             assert key in d, key
         assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64" and "workload" in d["config"]
         r = d["roofline"]
-        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
         assert "traffic" in r and r["achieved"] > 0
         # value = whole-job corrections / max-over-ranks time: consistent with ms_per_step
-        assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (d["n_gpus"] * 96 * 2) - 1.0) < 1e-9
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (d["n_gpus"] * 96 * 2) - 1.0) < 1e-6
 
 
 def test_launcher_rank_count_mismatch_is_refused():
@@ -108,10 +108,11 @@ def test_consistency_and_delayed_parity_on_the_drivers_command_line():
     a = _bench(["--steps", "20", "--warmup", "5"] + side)
     b = _bench(["--steps", "16", "--warmup", "4"] + side)
     for d, last in ((a, 25), (b, 20)):
+        # [nees_mean, nees_max, rmse_xy, rmse_theta, mean_trace_pose_cov, frac_nees_below_95pct, step] (bench.compact)
         mc = d["mc_consistency"]
-        assert mc["step"] == last
-        assert 0.5 < mc["nees_mean"] < 30.0 and mc["rmse_xy"] < 0.2 and mc["frac_nees_below_95pct"] > 0.3, mc
-    assert 1 / 3 < a["mc_consistency"]["nees_mean"] / b["mc_consistency"]["nees_mean"] < 3
+        assert mc[6] == last
+        assert 0.5 < mc[0] < 30.0 and mc[2] < 0.2 and mc[5] > 0.3, mc
+    assert 1 / 3 < a["mc_consistency"][0] / b["mc_consistency"][0] < 3
     for d, kd in ((a, 32), (b, 16)):
         dl = d["delayed_update"]
         assert dl["steps"] == kd and dl["parity_step"] == d["warmup"] + kd
@@ -132,7 +133,7 @@ def test_four_ranks_with_unequal_shards():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
     assert d["n_gpus"] == 4 and d["config"]["ranks_seen"] == 4 and d["config"]["filters_total"] == total
-    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (total * 2) - 1.0) < 1e-9     # every filter counted once
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (total * 2) - 1.0) < 1e-6     # every filter counted once
     assert d["rank_ms_per_step_min"] <= d["rank_ms_per_step_max"] == d["ms_per_step"]
     # side legs are not run at N > 1
     for key in ("call_fused_update", "active_set_update", "unknown_association", "small_map_monte_carlo", "configs_1"):
@@ -151,7 +152,35 @@ def test_two_ranks_run_the_delayed_legs():
     d = _line(r.stdout)
     dl = d["delayed_update"]
     assert d["n_gpus"] == 2 and dl["steps"] == 4 and dl["flushes"] == 2
-    assert abs(dl["value"] * dl["ms_per_step"] * 1e-3 / (2 * 40 * 2) - 1.0) < 1e-9       # both ranks' filters, 2 corrections each
+    assert abs(dl["value"] * dl["ms_per_step"] * 1e-3 / (2 * 40 * 2) - 1.0) < 1e-6       # both ranks' filters, 2 corrections each
     assert dl["max_abs_state_diff_vs_eager"] < 1e-9 and dl["symmetric"]["max_abs_state_diff_vs_eager"] < 1e-9
-    assert dl["symmetric"]["value"] > 0 and dl["symmetric"]["flush_form"].startswith("mirrored")
+    assert dl["symmetric"]["value"] > 0 and dl["symmetric"]["flush_form"] == "k_flush_sym"
 
+
+
+def test_one_rank_under_the_launcher_runs_the_rccl_path():
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` with the REAL backend: bench.py's own
+    init_process_group("nccl", device_id=...) (RCCL on ROCm), its barriers around the timed region and the scalar
+    all-reduces of shard.py run through RCCL on the device -- the very code path of the driver's N = 2, 4, 8 jobs, which this
+    one-GPU box cannot start (RCCL refuses two ranks on one device; the multi-rank tests above rendezvous over gloo).
+    The line must equal the launcher-less run's in everything but time."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("EKF_DIST_BACKEND", None)
+    args = ["--steps", "4", "--warmup", "1", "--filters", "96", "--landmarks", "300", "--no-cpu-baseline", "--no-active-set",
+            "--no-unknown", "--no-small", "--no-configs", "--no-call-fused", "--delayed-k", "8"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1"] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["config"]["collectives"] == "nccl" and d["config"]["ranks_seen"] == 1 and d["n_gpus"] == 1
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (96 * 2) - 1.0) < 1e-6
+    dl = d["delayed_update"]
+    assert dl["max_abs_state_diff_vs_eager"] < 1e-9 and abs(dl["value"] * dl["ms_per_step"] * 1e-3 / (96 * 2) - 1.0) < 1e-6
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, capture_output=True,
+                           text=True, timeout=900, env=env, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    p = _line(plain.stdout)
+    assert p["config"]["collectives"] is None
+    assert p["mc_consistency"] == d["mc_consistency"]            # same filters, same inputs, same end state
+    assert p["delayed_update"]["max_abs_state_diff_vs_eager"] == dl["max_abs_state_diff_vs_eager"]

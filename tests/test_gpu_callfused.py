@@ -248,3 +248,61 @@ def test_calls_with_more_than_64_readings(hip, n, J):
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
 
+
+
+def test_two_handles_driven_from_two_host_threads(hip, oracle):
+    """One handle is not thread-safe, but two handles are independent (own stream, own staging ring, own mapped result
+    block, thread-local error text): two host threads drive one EKF_SLAM object each through 50 ticks of the node loop
+    at the same time -- one known association (prediction + measurement, slam.cpp:433-434), one unknown
+    (prediction + data_association, unknown_data_assoc.cpp:414-415) -- and each ends where the checker ends.
+    ctypes releases the GIL around every C-ABI call, so the calls of the two threads do overlap."""
+    import threading
+    T = 50
+    klog = synth.make_known_log(synth.config2(steps=T))                       # n = 200, two launches per call
+    ucfg = synth.SimConfig(n=150, steps=T, filters=1, seed=81, half_extent=5.0, min_spacing=0.3, max_visible_dis=1.4, vmax=8,
+                           v_cmd=1.0, w_cmd=0.6)
+    ulog = synth.make_unknown_log(ucfg)
+    out, errs = {}, []
+    gate = threading.Barrier(2)
+
+    def known_side():
+        try:
+            f = hip.EKF_SLAM(200)
+            gate.wait()
+            _replay(f, klog, 0, T)
+            out["known"] = (f.state, f.cov)
+            f.close()
+        except Exception as e:   # (reported by the main thread)
+            errs.append(e)
+
+    def unknown_side():
+        try:
+            f = hip.EKF_SLAM(150)
+            known = np.zeros(150, dtype=np.uint8)
+            dec = []
+            gate.wait()
+            for t in range(T):
+                f.prediction(ulog.twist[t, 0])
+                dec.append(f.data_association(ulog.meas_xy[t, 0, :ulog.count[t, 0]], known).copy())
+            out["unknown"] = (f.state, f.cov, known, dec)
+            f.close()
+        except Exception as e:
+            errs.append(e)
+
+    th = [threading.Thread(target=known_side), threading.Thread(target=unknown_side)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    o = oracle.OracleEKF(200, oracle.STRUCTURED)
+    for t in range(T):
+        sensor, vis = klog.expand_step(t)
+        o.prediction(*klog.twist[t, 0]); o.measurement(sensor, vis)
+    assert_parity(out["known"][0], out["known"][1], o.state, o.cov, FP64_TOL, "known side, two threads")
+    o = oracle.OracleEKF(150, oracle.STRUCTURED)
+    known = np.zeros(150, dtype=np.uint8)
+    for t in range(T):
+        o.prediction(*ulog.twist[t, 0])
+        d = o.data_association(ulog.meas_xy[t, 0, :ulog.count[t, 0]], known)
+        assert np.array_equal(d, out["unknown"][3][t]), f"decisions of step {t}"
+    assert np.array_equal(known, out["unknown"][2])
+    assert_parity(out["unknown"][0], out["unknown"][1], o.state, o.cov, FP64_TOL, "unknown side, two threads")

@@ -285,6 +285,25 @@ def test_custom_gates(hip, oracle):
     f.close()
 
 
+@pytest.mark.parametrize("n", [4, 60, 150, 500])
+def test_initialised_then_dropped_landmark_keeps_its_position(hip, oracle, n):
+    """gate_update = 0: a reading that initialises a landmark (ekf_slam.cpp:318-327, position written at :321-322) is
+    then dropped at :330 (0.0 < 0.0 is false).  The position must be in the state on every launch form (LDS-resident,
+    whole call in one launch, per reading) -- round 3's advisor finding for k_assoc_call."""
+    p = hip.default_params()
+    p.gate_update = 0.0
+    tup = (p.sigma0_landmark, p.q_pose, p.r_meas, p.gate_new, p.gate_update, p.straight_eps)
+    f, o = hip.EKF_SLAM(n, params=p), oracle.OracleEKF(n, oracle.STRUCTURED, params=tup)
+    kf, ko = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    f.prediction((0.05, 0.1)); o.prediction(0.05, 0.1)
+    m = np.array([[1.0, 0.2], [-2.0, 1.5], [40.0, -30.0]])
+    a, b = f.data_association(m, kf), o.data_association(m, ko)
+    assert np.array_equal(a, b) and (a == -1).all() and np.array_equal(kf, ko) and kf.sum() >= 1
+    assert np.abs(o.state[3:5]).max() > 0.5
+    assert np.abs(f.state - o.state).max() < 1e-12
+    f.close()
+
+
 def test_degenerate_geometry_propagates_nan_like_the_reference(hip, oracle):
     """Landmark exactly at the robot position -> d = 0 -> division by zero (ekf_slam.cpp:160-166): the
     reference silently produces NaN; so must we (no crash, no hang, same NaN pattern)."""

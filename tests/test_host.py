@@ -112,6 +112,12 @@ def test_committed_bench_line_keeps_the_contract():
     path = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]", "bench_n1.json")))[-1]
     line = [l for l in open(path) if l.startswith("{")][0]
     d = json.loads(line)
+    # The driver keeps an 8 KB tail of the run: the whole line must fit it (round 3's 14.4 KB line lost the delayed leg
+    # -- the >= 1e6 figure -- and most side legs there).  bench.py asserts the same budget before it prints.
+    assert len(line) < 7500, len(line)
+    for k in ("delayed_update", "call_fused_update", "configs_1", "configs_2", "configs_3"):
+        assert k in d, k
+    assert {"value", "frac_of_8TBps", "max_abs_state_diff_vs_eager", "max_abs_state_diff_vs_cpu_port"} <= set(d["delayed_update"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -119,7 +125,7 @@ def test_committed_bench_line_keeps_the_contract():
     assert d["metric"] == base["metric"] and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 * r["frac"]
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
     c = d["cpu_baseline"]

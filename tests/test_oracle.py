@@ -16,6 +16,7 @@ from oracle.np_restatement import NumpyEKF, normalize_angle as np_normalize
 from parity import assert_parity, worst
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MIN_MARGIN = 1e-6   # tests/golden/make_golden.py's bar
 AGREE = 5e-12
 
 
@@ -163,13 +164,52 @@ def test_golden_unknown(oracle):
     for mode in (oracle.DENSE, oracle.STRUCTURED):
         o = oracle.OracleEKF(n, mode)
         known = np.zeros(n, dtype=np.uint8)
+        margins = oracle.new_margins()
         for t in range(T):
             J = int(g["count"][t])
             o.prediction(*g["twist"][t])
-            a = o.data_association(g["meas_xy"][t, :J], known)
+            a = o.data_association(g["meas_xy"][t, :J], known, margins)
             assert np.array_equal(a, g["assoc"][t, :J]), f"decisions differ at step {t}"
         assert np.array_equal(known, g["known"])
         assert_parity(o.state, o.cov, g["state"], g["cov"], AGREE, f"unknown mode {mode}")
+        # Decision margins stored with the fixture (make_golden.py refuses to write a thinner one): every score is at
+        # least 1e-6 (relative) away from the gates 10.0 / 1.0 (ekf_slam.cpp:293,305,330) and every winner at least that
+        # far ahead of the runner-up -- the oracle is unpinned, and this is where another summation order could matter.
+        assert g["margins"][:3].min() >= MIN_MARGIN
+        assert np.allclose(margins, g["margins"], rtol=1e-6, atol=0.0), (margins, g["margins"])
+
+
+def test_margins_are_recorded_per_scored_pair(oracle):
+    """The margin recorder itself: one landmark, readings placed so that the score lands at a known place."""
+    o = oracle.OracleEKF(3, oracle.DENSE)
+    known = np.zeros(3, dtype=np.uint8)
+    m = oracle.new_margins()
+    a = o.data_association(np.array([[1.0, 0.0]]), known, m)     # nothing to score yet: margins untouched
+    assert a[0] == 0 and np.isinf(m).all()
+    d = o.maha(1.0, 0.3, 0)
+    o.data_association(np.array([[1.0, 0.3]]), known, m)          # one scored pair, no runner-up
+    assert np.isclose(m[0], abs(d - 10.0) / 10.0) and np.isclose(m[1], abs(d - 1.0) / 1.0) and np.isinf(m[2])
+    assert np.isclose(m[3], d)
+    o.data_association(np.array([[-2.0, 1.0]]), known, m)         # far from landmark 0 -> second landmark
+    d0, d1 = o.maha(1.0, 0.25, 0), o.maha(1.0, 0.25, 1)
+    m2 = oracle.new_margins()
+    o.data_association(np.array([[1.0, 0.25]]), known, m2)        # two scored pairs: the gap is (runner-up - winner) / runner-up
+    lo, hi = min(d0, d1), max(d0, d1)
+    assert np.isclose(m2[2], (hi - lo) / hi) and np.isclose(m2[3], lo)
+
+
+def test_configs2_log_has_decision_margins(oracle):
+    """BASELINE.json configs[2] (synth.config3: n = 1000, unknown association, 2000 steps): bench.py's `configs_2`
+    leg prints min_gate_margin for exactly this log; here it is held to the fixtures' bar."""
+    cfg = synth.config3(steps=2000)
+    log = synth.make_unknown_log(cfg)
+    o = oracle.OracleEKF(cfg.n, oracle.STRUCTURED, fast=True)
+    known = np.zeros(cfg.n, dtype=np.uint8)
+    m = oracle.new_margins()
+    for t in range(cfg.steps):
+        o.prediction(*log.twist[t, 0])
+        o.data_association(log.meas_xy[t, 0, :log.count[t, 0]], known, m)
+    assert known.sum() > 200 and m[:3].min() >= MIN_MARGIN, dict(zip(oracle.MARGIN_KEYS, m))
 
 
 def test_golden_maha(oracle):
