@@ -148,34 +148,44 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
                 else g[k].x = Sg[(size_t)2 * ld + c];
             }
         }
-        // the factor rows of pairs j+2 and j+4 are in flight while pair j is folded in (trips past the end
-        // re-read pair 0): this loop streams count x 32 B per lane and is bandwidth-bound
-        auto ld4 = [&](int j, double2_t& a0, double2_t& a1, double2_t& b0, double2_t& b1) {
+        // The factor rows stream through a ring of THREE register stages (pairs j, j + 2, j + 4 in flight while pair j is
+        // folded in), unrolled by three so that a stage never changes registers: round 3's loop rotated the stages with
+        // copies (ua = ua1 ...), and a copy of a register that a load is still writing waits for that load -- hipcc put
+        // `s_waitcnt vmcnt(0)` at the top of every trip, i.e. ONE stage (64 B per lane) in flight: 4.0-4.8 TB/s of a
+        // kernel that streams count x 32 B per lane and is bandwidth-bound.  Trips past the end re-read pair 0.
+        struct Stage { double2_t ua, ub, va, vb; };
+        auto ld4 = [&](int j, Stage& q) {
+            const int jj = j < rc ? j : 0;
             if (!SYM) {
-                a0 = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
-                a1 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
+                q.ua = *reinterpret_cast<const double2_t*>(Ub + (size_t)jj * ld + r);
+                q.ub = *reinterpret_cast<const double2_t*>(Ub + (size_t)(jj + 1) * ld + r);
             }
-            b0 = *reinterpret_cast<const double2_t*>(Vb + (size_t)j * ld + r);
-            b1 = *reinterpret_cast<const double2_t*>(Vb + (size_t)(j + 1) * ld + r);
+            q.va = *reinterpret_cast<const double2_t*>(Vb + (size_t)jj * ld + r);
+            q.vb = *reinterpret_cast<const double2_t*>(Vb + (size_t)(jj + 1) * ld + r);
         };
-        double2_t ua = zero2, ub = zero2, va = zero2, vb = zero2, ua1 = zero2, ub1 = zero2, va1 = zero2, vb1 = zero2;
-        if (rc > 0) { ld4(0, ua, ub, va, vb); ld4(2 < rc ? 2 : 0, ua1, ub1, va1, vb1); }
-        for (int j = 0; j < rc; j += 2) {
-            double2_t ua2, ub2, va2, vb2;
-            ld4(j + 4 < rc ? j + 4 : 0, ua2, ub2, va2, vb2);
+        auto fold = [&](int j, const Stage& q) {
+            if (j >= rc) return;   // (uniform)
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 const double v5a = sh_V5[k * kMaxPending + j], v5b = sh_V5[k * kMaxPending + j + 1];
                 const double u5a = sh_U5[k * kMaxPending + j], u5b = sh_U5[k * kMaxPending + j + 1];
                 if (!SYM) {
-                    p[k].x = __builtin_fma(-ub.x, v5b, __builtin_fma(-ua.x, v5a, p[k].x));
-                    p[k].y = __builtin_fma(-ub.y, v5b, __builtin_fma(-ua.y, v5a, p[k].y));
+                    p[k].x = __builtin_fma(-q.ub.x, v5b, __builtin_fma(-q.ua.x, v5a, p[k].x));
+                    p[k].y = __builtin_fma(-q.ub.y, v5b, __builtin_fma(-q.ua.y, v5a, p[k].y));
                 }
-                g[k].x = __builtin_fma(-u5b, vb.x, __builtin_fma(-u5a, va.x, g[k].x));
-                g[k].y = __builtin_fma(-u5b, vb.y, __builtin_fma(-u5a, va.y, g[k].y));
+                g[k].x = __builtin_fma(-u5b, q.vb.x, __builtin_fma(-u5a, q.va.x, g[k].x));
+                g[k].y = __builtin_fma(-u5b, q.vb.y, __builtin_fma(-u5a, q.va.y, g[k].y));
             }
-            ua = ua1; ub = ub1; va = va1; vb = vb1;
-            ua1 = ua2; ub1 = ub2; va1 = va2; vb1 = vb2;
+        };
+        if (rc > 0) {
+            Stage s0, s1, s2;
+            s0.ua = s0.ub = s1.ua = s1.ub = s2.ua = s2.ub = zero2;
+            ld4(0, s0); ld4(2, s1);
+            for (int j = 0; j < rc; j += 6) {
+                ld4(j + 4, s2); fold(j, s0);
+                ld4(j + 6, s0); fold(j + 2, s1);
+                ld4(j + 8, s1); fold(j + 4, s2);
+            }
         }
         if (SYM) {
 #pragma unroll
@@ -378,32 +388,41 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     double2_t k1a = zero2, k1b = zero2, g1a = zero2, g1b = zero2, k2a = zero2, k2b = zero2, g2a = zero2, g2b = zero2;
     double2_t snew = zero2;
     if (row_live) {
-        auto ld4 = [&](int j, double2_t& a0, double2_t& a1, double2_t& b0, double2_t& b1) {
+        // three register stages, unrolled by three (see k_gain_delayed: no rotating copies, so that pairs j + 2 and j + 4
+        // really are in flight while pair j is folded in)
+        struct Stage { double2_t ua, ub, va, vb; };
+        auto ld4 = [&](int j, Stage& q) {
+            const int jj = j < rc ? j : 0;
             if (!SYM) {
-                a0 = *reinterpret_cast<const double2_t*>(Ub + (size_t)j * ld + r);
-                a1 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(j + 1) * ld + r);
+                q.ua = *reinterpret_cast<const double2_t*>(Ub + (size_t)jj * ld + r);
+                q.ub = *reinterpret_cast<const double2_t*>(Ub + (size_t)(jj + 1) * ld + r);
             }
-            b0 = *reinterpret_cast<const double2_t*>(Vb + (size_t)j * ld + r);
-            b1 = *reinterpret_cast<const double2_t*>(Vb + (size_t)(j + 1) * ld + r);
+            q.va = *reinterpret_cast<const double2_t*>(Vb + (size_t)jj * ld + r);
+            q.vb = *reinterpret_cast<const double2_t*>(Vb + (size_t)(jj + 1) * ld + r);
         };
-        double2_t ua = zero2, ub = zero2, va = zero2, vb = zero2, ua1 = zero2, ub1 = zero2, va1 = zero2, vb1 = zero2;
-        if (rc > 0) { ld4(0, ua, ub, va, vb); ld4(2 < rc ? 2 : 0, ua1, ub1, va1, vb1); }
-        for (int j = 0; j < rc; j += 2) {
-            double2_t ua2, ub2, va2, vb2;
-            ld4(j + 4 < rc ? j + 4 : 0, ua2, ub2, va2, vb2);
+        auto fold = [&](int j, const Stage& q) {
+            if (j >= rc) return;   // (uniform)
 #pragma unroll
             for (int k = 0; k < 7; k++) {
                 const double v5a = sh_V7[k * kMaxPending + j], v5b = sh_V7[k * kMaxPending + j + 1];
                 const double u5a = sh_U7[k * kMaxPending + j], u5b = sh_U7[k * kMaxPending + j + 1];
                 if (!SYM) {
-                    p[k].x = __builtin_fma(-ub.x, v5b, __builtin_fma(-ua.x, v5a, p[k].x));
-                    p[k].y = __builtin_fma(-ub.y, v5b, __builtin_fma(-ua.y, v5a, p[k].y));
+                    p[k].x = __builtin_fma(-q.ub.x, v5b, __builtin_fma(-q.ua.x, v5a, p[k].x));
+                    p[k].y = __builtin_fma(-q.ub.y, v5b, __builtin_fma(-q.ua.y, v5a, p[k].y));
                 }
-                g[k].x = __builtin_fma(-u5b, vb.x, __builtin_fma(-u5a, va.x, g[k].x));
-                g[k].y = __builtin_fma(-u5b, vb.y, __builtin_fma(-u5a, va.y, g[k].y));
+                g[k].x = __builtin_fma(-u5b, q.vb.x, __builtin_fma(-u5a, q.va.x, g[k].x));
+                g[k].y = __builtin_fma(-u5b, q.vb.y, __builtin_fma(-u5a, q.va.y, g[k].y));
             }
-            ua = ua1; ub = ub1; va = va1; vb = vb1;
-            ua1 = ua2; ub1 = ub2; va1 = va2; vb1 = vb2;
+        };
+        if (rc > 0) {
+            Stage s0, s1, s2;
+            s0.ua = s0.ub = s1.ua = s1.ub = s2.ua = s2.ub = zero2;
+            ld4(0, s0); ld4(2, s1);
+            for (int j = 0; j < rc; j += 6) {
+                ld4(j + 4, s2); fold(j, s0);
+                ld4(j + 6, s0); fold(j + 2, s1);
+                ld4(j + 8, s1); fold(j + 4, s2);
+            }
         }
         if (SYM) {
 #pragma unroll
@@ -491,24 +510,32 @@ template <int U_ROWS>
 __device__ __forceinline__ void flush_apply(double2_t (&a)[U_ROWS], const double* __restrict__ Ub,
                                             const double2_t* __restrict__ Vb, int r, int ld, int ld2n, int count) {
     // V of pair j+2 AND j+4 are in flight while pair j's FMAs run (PMC: with one pair of lookahead the waves
-    // sat in s_waitcnt half of the time: an L2 hit under load outlasts one pair's 256 FMA cycles).  Trips past
-    // the end re-read pair 0.
-    const int j1 = 2 < count ? 2 : 0;
-    double2_t v0 = Vb[0], v1 = Vb[ld2n];
-    double2_t v0n = Vb[(size_t)j1 * ld2n], v1n = Vb[(size_t)(j1 + 1) * ld2n];
-    for (int j = 0; j < count; j += 2) {
-        const int jn = j + 4 < count ? j + 4 : 0;
-        const double2_t v0nn = Vb[(size_t)jn * ld2n], v1nn = Vb[(size_t)(jn + 1) * ld2n];
+    // sat in s_waitcnt half of the time: an L2 hit under load outlasts one pair's 256 FMA cycles).  Three register
+    // stages, unrolled by three: stages rotated by copies make hipcc wait for every load at the top of each trip (a copy
+    // of a register that a load is still writing waits for that load).  Trips past the end re-read pair 0.
+    struct Stage { double2_t v0, v1; };
+    auto ldv = [&](int j, Stage& q) {
+        const int jj = j < count ? j : 0;
+        q.v0 = Vb[(size_t)jj * ld2n];
+        q.v1 = Vb[(size_t)(jj + 1) * ld2n];
+    };
+    auto fold = [&](int j, const Stage& q) {
+        if (j >= count) return;   // (uniform)
         const double* __restrict__ u0 = Ub + (size_t)j * ld + r;  // wave-uniform -> scalar loads
         const double* __restrict__ u1 = u0 + ld;
 #pragma unroll
         for (int u = 0; u < U_ROWS; u++) {
             const double k0 = -u0[u], k1 = -u1[u];
-            a[u].x = __builtin_fma(k1, v1.x, __builtin_fma(k0, v0.x, a[u].x));
-            a[u].y = __builtin_fma(k1, v1.y, __builtin_fma(k0, v0.y, a[u].y));
+            a[u].x = __builtin_fma(k1, q.v1.x, __builtin_fma(k0, q.v0.x, a[u].x));
+            a[u].y = __builtin_fma(k1, q.v1.y, __builtin_fma(k0, q.v0.y, a[u].y));
         }
-        v0 = v0n; v1 = v1n;
-        v0n = v0nn; v1n = v1nn;
+    };
+    Stage s0, s1, s2;
+    ldv(0, s0); ldv(2, s1);
+    for (int j = 0; j < count; j += 6) {
+        ldv(j + 4, s2); fold(j, s0);
+        ldv(j + 6, s0); fold(j + 2, s1);
+        ldv(j + 8, s1); fold(j + 4, s2);
     }
 }
 

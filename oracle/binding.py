@@ -88,11 +88,11 @@ def _d(a):
 
 
 DENSE, STRUCTURED = 0, 1
-MARGIN_KEYS = ("to_gate_new", "to_gate_update", "winner_to_runner_up", "smallest_score")
+MARGIN_KEYS = ("to_gate_new", "to_gate_update", "winner_to_runner_up", "smallest_score", "decision_relevant")
 
 
 def new_margins():
-    return np.full(4, np.inf)
+    return np.full(5, np.inf)
 
 
 class OracleEKF:
@@ -132,13 +132,13 @@ class OracleEKF:
 
     def data_association(self, meas_xy, known, margins=None):
         """known: uint8[n] numpy array, modified in place; returns per-measurement landmark (-1 dropped).
-        margins: optional float64[4] (new_margins()), MIN-accumulated over calls: relative distance of every score to
-        gate_new / gate_update, winner-to-runner-up gap, smallest score (ekf_oracle.c, ekfo_data_association_m)."""
+        margins: optional float64[5] (new_margins()), MIN-accumulated over calls: relative distance of every score to
+        gate_new / gate_update, winner-to-runner-up gap, smallest score, decision-relevant minimum (ekf_oracle.c, ekfo_data_association_m)."""
         m = np.ascontiguousarray(meas_xy, dtype=np.float64).reshape(-1, 2)
         assert known.dtype == np.uint8 and known.size == self.n and known.flags.c_contiguous
         assoc = np.full(len(m), -1, dtype=np.int32)
         if margins is not None:
-            assert margins.dtype == np.float64 and margins.size == 4 and margins.flags.c_contiguous
+            assert margins.dtype == np.float64 and margins.size == 5 and margins.flags.c_contiguous
             self._lib.ekfo_data_association_m(self._h, _d(m), len(m), known.ctypes.data_as(_bp),
                                               assoc.ctypes.data_as(_ip), _d(margins))
             return assoc

@@ -434,14 +434,18 @@ double ekfo_maha(ekfo *o, double sx, double sy, int i) {
  * number of corrections applied; assoc_out (J ints, nullable) records the
  * landmark each measurement was matched to (-1 = dropped).
  *
- * margins (nullable, 4 doubles, MIN-accumulated: the caller starts them at
+ * margins (nullable, 5 doubles, MIN-accumulated: the caller starts them at
  * +inf) records how far the discrete decisions of :293-330 sit from flipping --
  * the only place where another summation order (real Armadillo / BLAS against
  * this restatement) could change a result by more than rounding:
  *   [0] min over every scored (reading, landmark) pair of |d - gate_new| / gate_new       (:293,305)
  *   [1] min over every scored pair of |d - gate_update| / gate_update                     (:330)
  *   [2] min over readings with a winner of (runner_up - winner) / runner_up               (:305-309)
- *   [3] min over every scored pair of d itself (a score is a positive-definite form)      */
+ *   [3] min over every scored pair of d itself (a score is a positive-definite form)
+ *   [4] the DECISION-RELEVANT minimum: per reading only the smallest score d1 takes part in a comparison whose
+ *       outcome matters (:305-309 keeps the first strict minimum) -- min of |d1 - gate_new| / gate_new,
+ *       |d1 - gate_update| / gate_update (when d1 < gate_new) and the gap [2].  [0], [1] are stricter: they also
+ *       count pairs that lose to another landmark whatever side of a gate they fall on.          */
 int ekfo_data_association_m(ekfo *o, const double *meas_xy, int J, unsigned char *known, int *assoc_out,
                             double *margins) {
     int known_count = 0;
@@ -468,6 +472,15 @@ int ekfo_data_association_m(ekfo *o, const double *meas_xy, int J, unsigned char
         if (margins && min_maha_idx < known_count && second < INFINITY) {
             double g = (second - first) / second;
             if (g < margins[2]) margins[2] = g;
+            if (g < margins[4]) margins[4] = g;
+        }
+        if (margins && first < INFINITY) {
+            double a = fabs(first - o->p.gate_new) / o->p.gate_new;
+            if (a < margins[4]) margins[4] = a;
+            if (first < o->p.gate_new) {
+                double b = fabs(first - o->p.gate_update) / o->p.gate_update;
+                if (b < margins[4]) margins[4] = b;
+            }
         }
         if (min_maha_idx == known_count && min_maha_idx < o->n) { /* :318-327 */
             initialize_landmark(o, mx, my, min_maha_idx);
