@@ -50,7 +50,8 @@ SYMBOLS = [
 FORM_SMALL_MAP, FORM_FUSED_CORRECTION, FORM_CALL_FUSED, FORM_ACTIVE_PREFIX = 1 << 0, 1 << 1, 1 << 2, 1 << 3
 FORM_STEP_FUSED, FORM_STEP_SPLIT_PASS, FORM_DELAYED_PAIR, FORM_ROW_PACKING = 1 << 4, 1 << 5, 1 << 6, 1 << 7
 FORM_STRIP_FLUSH, FORM_STRIP_FLUSH_ALWAYS = 1 << 8, 1 << 9
-FORMS_DEFAULT = (1 << 9) - 1
+FORM_COLUMN_PANEL, FORM_COLUMN_PANEL_ONE_SLOT = 1 << 10, 1 << 11
+FORMS_DEFAULT = ((1 << 9) - 1) | FORM_COLUMN_PANEL
 
 
 class EkfError(RuntimeError):
@@ -532,11 +533,12 @@ class BatchEKF:
 
     def form_counts(self):
         """covariance passes per form since creation: plain / strip flushes, paired delayed gain launches, call-fused
-        passes, per-landmark rank-2 streams, step-fused launches with a separate pass, mirrored flushes"""
+        passes, per-landmark rank-2 streams, step-fused launches with a separate pass, mirrored flushes, delayed gain
+        launches that read the column panel"""
         c = (C.c_longlong * 8)()
         _check(self._lib.ekf_batch_form_counts(self._h, c))
         return dict(zip(("flush_plain", "flush_strip", "gain_pairs", "call_fused_passes", "rank2_streams", "step_split_passes",
-                         "flush_mirrored"), (int(x) for x in c)))
+                         "flush_mirrored", "gain_from_panel"), (int(x) for x in c)))
 
     def set_active_prefix(self, enable=True):
         self._form(FORM_ACTIVE_PREFIX, enable)

@@ -132,6 +132,7 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
     Pool& P = hb->pool;
     if (P.T <= 0) return fail(EKF_ERR_STATE, "ekf_batch_run_known: no log uploaded");
     if (t_begin < 0 || t_end > P.T || t_begin > t_end) return fail(EKF_ERR_INVALID, "step range outside the uploaded log");
+    const bool panel_valid_in = P.panel_valid;   // (use() clears it: see Pool::colp)
     EKFC(P.use());
     const int B = P.pv.B, vmax = P.vmax;
     P.touched_hwm = P.pv.n;  // a known log corrects arbitrary indices: no discovered-prefix structure afterwards
@@ -158,13 +159,49 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
     HIPC(hipEventRecord(P.ev_begin, P.stream));
     size_t k = 0;
     bool cols_stale = false;   // (see upper_run below)
-    auto timed_flush = [&]() -> ekf_status {
+    // Column panel (EKF_FORM_COLUMN_PANEL; Pending::colp): every flush of the run writes the columns 0..2 and the columns
+    // of the landmarks the NEXT corrections touch (the log is on the device) as contiguous panel rows; while a panel is
+    // on, the gain kernels read those columns coalesced and prediction() keeps columns 0..2 current in the panel instead
+    // of in the matrix.  A run whose closing flush wrote a panel hands it to the next run (panel_valid).
+    const bool panel_capable = P.pend_cap >= 4 && !P.pend_symmetric && P.column_panel && !P.active_set && P.pv.n > 0 &&
+                               P.pv.N >= 256 && t_end > t_begin;
+    bool panel_fresh = false;
+    if (panel_capable) EKFC(P.ensure_panel(&panel_fresh));
+    bool panel_on = panel_capable && panel_valid_in && !panel_fresh && P.pend_count == 0;
+    bool panel_cols_stale = false;   // predictions since the last flush while the panel was on: matrix columns 1, 2 are behind
+    P.panel_active = panel_on;
+    // t_next: the first log step with corrections behind this flush (its slots and those of the following steps, up to
+    // the capacity of the factor store, are what the panel is planned for)
+    auto timed_flush = [&](int t_next) -> ekf_status {
         if (P.pend_count == 0) return EKF_OK;
+        ekf::PanelIO pio{nullptr, nullptr, nullptr, 0};
+        if (panel_capable) {
+            pio.rows = P.colp_rows();
+            if (panel_on) pio.in = P.colp;
+            if (t_next < P.T) {
+                int h = 0, vecs = 0;
+                for (int tt = t_next; tt < P.T; tt++) {
+                    int a = 0;
+                    for (int v = 0; v < vmax; v++) a += P.slot_active[(size_t)tt * vmax + v] > 0;
+                    if (h > 0 && vecs + 2 * a > P.pend_cap) break;
+                    vecs += 2 * a;
+                    h++;
+                }
+                ekf::launch_panel_plan(P.pv, P.log_lm + (size_t)t_next * B * vmax, h, vmax, P.colp_slots, P.lmslot,
+                                       P.plan_list, P.stream);
+                pio.out = P.colp;
+                pio.lmslot = P.lmslot;
+            }
+        }
+        P.panel_active = false;   // (the flush itself takes the panel through pio)
         if (ev) HIPC(hipEventRecord(ev[2 * k], P.stream));
-        EKFC(P.flush());
+        EKFC(P.flush(pio));
         if (ev) HIPC(hipEventRecord(ev[2 * k + 1], P.stream));
         k++;
         cols_stale = false;    // (a mirroring flush rewrites everything below the diagonal squares)
+        panel_on = pio.out != nullptr;
+        panel_cols_stale = false;
+        P.panel_active = panel_on;
         return EKF_OK;
     };
     ekf::CmdSrc src{};
@@ -194,6 +231,7 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
     for (int t = small_run ? t_end : t_begin; t < t_end; t++) {
         ekf::Pending pdp = P.pending();
         if (upper_run) { pdp.symmetric = 2; cols_stale = true; }
+        if (panel_on) panel_cols_stale = true;
         ekf::launch_predict(P.pv, P.log_twist + (size_t)t * B * 2, 0.0, 0.0, pdp, P.stream);  // prediction()
         ekf::launch_measure_begin(P.pv, P.log_init, !P.init_flag, P.stream);               // measurement() top
         P.init_flag = 1;
@@ -227,12 +265,12 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
             if (delayed) {
                 // two consecutive slots in one launch: the pending factor rows are read once for both corrections
                 if (P.delayed_pair && P.pend_cap >= 4 && v + 1 < vmax && P.slot_active[(size_t)t * vmax + v + 1] > 0) {
-                    if (P.pend_count + 4 > P.pend_cap) EKFC(timed_flush());
+                    if (P.pend_count + 4 > P.pend_cap) EKFC(timed_flush(t));
                     EKFC(P.correct_pair(src));
                     v++;
                     continue;
                 }
-                if (P.pend_count + 2 > P.pend_cap) EKFC(timed_flush());
+                if (P.pend_count + 2 > P.pend_cap) EKFC(timed_flush(t));
                 EKFC(P.correct(src));
             } else {
                 ekf::launch_gain(P.pv, src, P.stream);
@@ -245,8 +283,11 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
             }
         }
     }
-    if (delayed) EKFC(timed_flush());  // every run leaves Sigma materialised
+    if (delayed) EKFC(timed_flush(t_end));  // every run leaves Sigma materialised
     if (cols_stale) ekf::launch_sym_repair(P.pv, P.stream);   // (predictions after the last flush)
+    if (panel_on && panel_cols_stale) ekf::launch_panel_repair(P.pv, P.colp, P.colp_rows(), P.stream);   // (the same, panel form)
+    P.panel_active = false;
+    P.panel_valid = panel_on;   // the panel holds the columns of the covariance as this run leaves it
     const size_t passes = k;
     HIPC(hipEventRecord(P.ev_end, P.stream));
     EKFC(checked_launch());

@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
     }
 
     const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    // column panel (see Pending): columns 0..2 of Sigma_base, and the columns of planned landmarks, as contiguous rows; the
+    // matrix's own columns 1, 2 are stale below the pose block while it is on
+    const double* __restrict__ cp = (!SYM && pend.colp) ? pend.colp + (size_t)b * pend.colp_rows * ld : nullptr;
+    const int slot = cp ? pend.lmslot[(size_t)b * pv.n + lm] : -1;
     for (int idx = tid; idx < 5 * rc; idx += 256) {
         const int k = idx / rc, j = idx - k * rc;
         const int c = idx5(k, lm);
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
         const int k = tid / 5, l = tid % 5;
         double v = SYM ? Sg[(size_t)min(idx5(k, lm), idx5(l, lm)) * ld + max(idx5(k, lm), idx5(l, lm))]   // (upper triangle)
                        : Sg[(size_t)idx5(k, lm) * ld + idx5(l, lm)];
+        if (cp && k >= 3 && (l == 1 || l == 2)) v = cp[(size_t)l * ld + idx5(k, lm)];   // Sigma(c, 1), Sigma(c, 2)
         for (int j = 0; j < rc; j += 2)
             v = __builtin_fma(-sh_U5[k * kMaxPending + j + 1], sh_V5[l * kMaxPending + j + 1],
                               __builtin_fma(-sh_U5[k * kMaxPending + j], sh_V5[l * kMaxPending + j], v));
@@ -141,8 +146,17 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
             const int c = idx5(k, lm);
             g[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)c * ld + r);
             if (!SYM) {
-                p[k].x = Sg[(size_t)r * ld + c];
-                p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
+                if (cp && (k < 3 || slot >= 0)) {   // the column as a panel row: one coalesced 16-byte load
+                    p[k] = *reinterpret_cast<const double2_t*>(cp + (size_t)(k < 3 ? k : 3 + 2 * slot + (k - 3)) * ld + r);
+                    if (!two) p[k].y = 0.0;
+                } else {
+                    p[k].x = Sg[(size_t)r * ld + c];
+                    p[k].y = two ? Sg[(size_t)(r + 1) * ld + c] : 0.0;
+                }
+                if (cp && r < 4 && k >= 3) {   // Sigma(c, 1), Sigma(c, 2): the matrix's columns 1, 2 live in the panel
+                    if (r == 0) g[k].y = cp[(size_t)1 * ld + c];
+                    else g[k].x = cp[(size_t)2 * ld + c];
+                }
             } else if (r < 4 && k >= 3) {   // Sigma(c, 1), Sigma(c, 2) from the rows 1, 2 (see Pending::symmetric == 2)
                 if (r == 0) g[k].y = Sg[(size_t)1 * ld + c];
                 else g[k].x = Sg[(size_t)2 * ld + c];
@@ -272,6 +286,10 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     auto posB = [](int k) { return k < 3 ? k : k + 2; };
 
     const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    // column panel (see Pending; k_gain_delayed)
+    const double* __restrict__ cp = (!SYM && pend.colp) ? pend.colp + (size_t)b * pend.colp_rows * ld : nullptr;
+    const int slot1 = cp ? pend.lmslot[(size_t)b * pv.n + lm1] : -1;
+    const int slot2 = cp ? pend.lmslot[(size_t)b * pv.n + lmB] : -1;
     // The lane's base entries Sigma(r, C[k]) and Sigma(C[k], r) are requested FIRST: they depend on nothing but the two
     // landmarks, and the workgroup's latency-bound prologue below (core block, the two corrections' terms on one lane,
     // three barriers: a tenth of a workgroup's life) then runs while they are in flight.
@@ -289,14 +307,42 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
             }
         }
         if (!SYM) {
-            // the seven column entries of a row as four loads: {0, 1}, {2}, and the two landmarks' neighbouring pairs
             const double* rw0 = Sg + (size_t)r * ld;
             const double* rw1 = Sg + (size_t)(two ? r + 1 : r) * ld;
-            const D2u a0 = *reinterpret_cast<const D2u*>(rw0), a1 = *reinterpret_cast<const D2u*>(rw1);
-            const D2u b0 = *reinterpret_cast<const D2u*>(rw0 + cidx(3)), b1 = *reinterpret_cast<const D2u*>(rw1 + cidx(3));
-            const D2u c0 = *reinterpret_cast<const D2u*>(rw0 + cidx(5)), c1 = *reinterpret_cast<const D2u*>(rw1 + cidx(5));
-            p[0].x = a0.x; p[1].x = a0.y; p[2].x = rw0[2]; p[3].x = b0.x; p[4].x = b0.y; p[5].x = c0.x; p[6].x = c0.y;
-            p[0].y = a1.x; p[1].y = a1.y; p[2].y = rw1[2]; p[3].y = b1.x; p[4].y = b1.y; p[5].y = c1.x; p[6].y = c1.y;
+            if (cp) {
+                // panel on: every column that has a panel row is ONE coalesced 16-byte load (r, r + 1 are neighbours in the
+                // row); a landmark the plan did not hold is gathered from the matrix (its columns are current there)
+#pragma unroll
+                for (int k = 0; k < 3; k++) p[k] = *reinterpret_cast<const double2_t*>(cp + (size_t)k * ld + r);
+                if (slot1 >= 0) {
+                    p[3] = *reinterpret_cast<const double2_t*>(cp + (size_t)(3 + 2 * slot1) * ld + r);
+                    p[4] = *reinterpret_cast<const double2_t*>(cp + (size_t)(4 + 2 * slot1) * ld + r);
+                } else {
+                    const D2u b0 = *reinterpret_cast<const D2u*>(rw0 + cidx(3)), b1 = *reinterpret_cast<const D2u*>(rw1 + cidx(3));
+                    p[3].x = b0.x; p[4].x = b0.y; p[3].y = b1.x; p[4].y = b1.y;
+                }
+                if (slot2 >= 0) {
+                    p[5] = *reinterpret_cast<const double2_t*>(cp + (size_t)(3 + 2 * slot2) * ld + r);
+                    p[6] = *reinterpret_cast<const double2_t*>(cp + (size_t)(4 + 2 * slot2) * ld + r);
+                } else {
+                    const D2u c0 = *reinterpret_cast<const D2u*>(rw0 + cidx(5)), c1 = *reinterpret_cast<const D2u*>(rw1 + cidx(5));
+                    p[5].x = c0.x; p[6].x = c0.y; p[5].y = c1.x; p[6].y = c1.y;
+                }
+                if (r < 4) {   // Sigma(c, 1), Sigma(c, 2) for the landmark rows c: the matrix's columns 1, 2 live in the panel
+#pragma unroll
+                    for (int k = 3; k < 7; k++) {
+                        if (r == 0) g[k].y = cp[(size_t)1 * ld + cidx(k)];
+                        else g[k].x = cp[(size_t)2 * ld + cidx(k)];
+                    }
+                }
+            } else {
+                // the seven column entries of a row as four loads: {0, 1}, {2}, and the two landmarks' neighbouring pairs
+                const D2u a0 = *reinterpret_cast<const D2u*>(rw0), a1 = *reinterpret_cast<const D2u*>(rw1);
+                const D2u b0 = *reinterpret_cast<const D2u*>(rw0 + cidx(3)), b1 = *reinterpret_cast<const D2u*>(rw1 + cidx(3));
+                const D2u c0 = *reinterpret_cast<const D2u*>(rw0 + cidx(5)), c1 = *reinterpret_cast<const D2u*>(rw1 + cidx(5));
+                p[0].x = a0.x; p[1].x = a0.y; p[2].x = rw0[2]; p[3].x = b0.x; p[4].x = b0.y; p[5].x = c0.x; p[6].x = c0.y;
+                p[0].y = a1.x; p[1].y = a1.y; p[2].y = rw1[2]; p[3].y = b1.x; p[4].y = b1.y; p[5].y = c1.x; p[6].y = c1.y;
+            }
             if (!two) {
 #pragma unroll
                 for (int k = 0; k < 7; k++) p[k].y = 0.0;
@@ -314,6 +360,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
         const int k = tid / 7, l = tid % 7;
         double v = SYM ? Sg[(size_t)min(cidx(k), cidx(l)) * ld + max(cidx(k), cidx(l))]   // (upper triangle)
                        : Sg[(size_t)cidx(k) * ld + cidx(l)];
+        if (cp && k >= 3 && (l == 1 || l == 2)) v = cp[(size_t)l * ld + cidx(k)];   // Sigma(c, 1), Sigma(c, 2)
         for (int j = 0; j < rc; j += 2)
             v = __builtin_fma(-sh_U7[k * kMaxPending + j + 1], sh_V7[l * kMaxPending + j + 1],
                               __builtin_fma(-sh_U7[k * kMaxPending + j], sh_V7[l * kMaxPending + j], v));
@@ -489,6 +536,14 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
 // before stores, non-temporal), with a loop over the pairs: U values are wave-uniform (scalar loads),
 // V values are per lane and come from L2 (count x 16 KB per filter).  2*8*N^2 bytes, 2*count*N^2 flop.
 // ---------------------------------------------------------------------------------------------
+// Column panel (see Pending): the panel row that holds column `col` of Sigma_base, or -1
+__device__ __forceinline__ int panel_row_of(int col, int N, const short* __restrict__ lms) {
+    if (col < 3) return col;
+    if (col >= N) return -1;
+    const int sl = lms[(col - 3) >> 1];
+    return sl >= 0 ? 3 + 2 * sl + ((col - 3) & 1) : -1;
+}
+
 template <int U_ROWS, bool NT>
 __device__ __forceinline__ void flush_load(double2_t (&a)[U_ROWS], const double2_t* col, int r, int ld2n) {
 #pragma unroll
@@ -546,7 +601,7 @@ template <int U_ROWS, bool NT>
 __global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const double* __restrict__ Uall,
                                                const double* __restrict__ Vall, int N, int ld, size_t sigma_stride,
                                                int cap, int count, int rows_per_block, int strips,
-                                               int row_blocks, int B) {
+                                               int row_blocks, int B, PanelIO pio, int n) {
     // 1-D grid, XCD-aware decode (speed only): workgroup ids are dealt round-robin to the 8 XCDs, each with
     // its own 4 MB L2.  All workgroups of one filter re-read that filter's factors (count x 32 KB), so a
     // filter is given to ONE XCD: id -> (xcd = id % 8, slot = id / 8), filter = 8 * (slot / P) + xcd.
@@ -571,18 +626,41 @@ __global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const
     const double2_t* __restrict__ Vb = reinterpret_cast<const double2_t*>(Vall + (size_t)b * cap * ld) + c2;
     double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + c2;
 
+    // column panel: columns 1, 2 of the base come from the panel that has been on (pio.in), and the new values of the
+    // planned columns go out as panel rows (pio.out) -- per lane at most two of its 2 x U_ROWS values per group
+    const double* __restrict__ pin = pio.in ? pio.in + (size_t)b * pio.rows * ld : nullptr;
+    double* __restrict__ pout = pio.out ? pio.out + (size_t)b * pio.rows * ld : nullptr;
+    const bool fix1 = pin && c2 == 0, fix2 = pin && c2 == 1;   // column 1 = .y of double2 0, column 2 = .x of double2 1
+    int prow0 = -1, prow1 = -1;
+    if (pout) {
+        const short* lms = pio.lmslot + (size_t)b * n;
+        prow0 = panel_row_of(2 * c2, N, lms);
+        prow1 = panel_row_of(2 * c2 + 1, N, lms);
+    }
+    auto panel_in = [&](auto& a, int r0, int rows) {
+        if (fix1) for (int u = 0; u < rows; u++) a[u].y = pin[(size_t)ld + r0 + u];
+        if (fix2) for (int u = 0; u < rows; u++) a[u].x = pin[(size_t)2 * ld + r0 + u];
+    };
+    auto panel_out = [&](const auto& a, int r0, int rows) {
+        if (prow0 >= 0) for (int u = 0; u < rows; u++) pout[(size_t)prow0 * ld + r0 + u] = a[u].x;
+        if (prow1 >= 0) for (int u = 0; u < rows; u++) pout[(size_t)prow1 * ld + r0 + u] = a[u].y;
+    };
     int r = row_begin;
     for (; r + U_ROWS <= row_end; r += U_ROWS) {
         double2_t a[U_ROWS];
         flush_load<U_ROWS, NT>(a, col, r, ld2n);
+        panel_in(a, r, U_ROWS);
         flush_apply<U_ROWS>(a, Ub, Vb, r, ld, ld2n, count);
         flush_store<U_ROWS, NT>(a, col, r, ld2n);
+        panel_out(a, r, U_ROWS);
     }
     for (; r < row_end; r++) {
         double2_t a[1];
         flush_load<1, false>(a, col, r, ld2n);
+        panel_in(a, r, 1);
         flush_apply<1>(a, Ub, Vb, r, ld, ld2n, count);
         flush_store<1, false>(a, col, r, ld2n);
+        panel_out(a, r, 1);
     }
 }
 
@@ -689,7 +767,8 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
                                                                      const double* __restrict__ Uall,
                                                                      const double* __restrict__ Vall, int N, int ld,
                                                                      size_t sigma_stride, int cap, int count,
-                                                                     int rows_per_block, int strips, int row_blocks, int B) {
+                                                                     int rows_per_block, int strips, int row_blocks, int B,
+                                                                     PanelIO pio, int n) {
     extern __shared__ double2_t sh_V[];   // [count][kStripCols2]
     const int P = strips * row_blocks;
     int b, p;
@@ -719,9 +798,35 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
     const int ngroups = (row_end - row_begin + 7) >> 3;
     int g = wave;
     double2_t a[8][2];
+    // column panel (see k_flush): at most four of a lane's 32 values per group are panel entries
+    const double* __restrict__ pin = pio.in ? pio.in + (size_t)b * pio.rows * ld : nullptr;
+    double* __restrict__ pout = pio.out ? pio.out + (size_t)b * pio.rows * ld : nullptr;
+    const bool fix1 = pin && cbase == 0, fix2 = pin && cbase == 1;
+    int prow[4] = {-1, -1, -1, -1};
+    if (pout) {
+        const short* lms = pio.lmslot + (size_t)b * n;
+        if (live0) { prow[0] = panel_row_of(2 * cbase, N, lms); prow[1] = panel_row_of(2 * cbase + 1, N, lms); }
+        if (live1) { prow[2] = panel_row_of(2 * cbase + 128, N, lms); prow[3] = panel_row_of(2 * cbase + 129, N, lms); }
+    }
+    const bool any_out = (prow[0] & prow[1] & prow[2] & prow[3]) >= 0;   // (some row index is not -1)
+    auto panel_in = [&](int r0) {
+        if (fix1) for (int u = 0; u < 8; u++) a[u][0].y = pin[(size_t)ld + min(r0 + u, row_end - 1)];
+        if (fix2) for (int u = 0; u < 8; u++) a[u][0].x = pin[(size_t)2 * ld + min(r0 + u, row_end - 1)];
+    };
+    auto panel_out = [&](int r0) {
+        if (!any_out) return;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (prow[q] < 0) continue;
+            double* dst = pout + (size_t)prow[q] * ld + r0;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (r0 + u < row_end) dst[u] = (q & 1) ? a[u][q >> 1].y : a[u][q >> 1].x;
+        }
+    };
     // the first group's loads go out BEFORE the V strip is staged: the two latencies overlap (a workgroup that owns a
     // few hundred rows only would otherwise spend ~10 % of its life in front of the barrier)
-    if (g < ngroups) fl_load<NT>(a, col, row_begin + 8 * g, row_end - 1, ld2n, live0, live1);
+    if (g < ngroups) { fl_load<NT>(a, col, row_begin + 8 * g, row_end - 1, ld2n, live0, live1); panel_in(row_begin + 8 * g); }
 
     const double2_t zero2 = {0.0, 0.0};
     {   // V strip -> LDS: wave w stages the vectors w, w + 16, ... (up to kStripMaxVec / 16 = 5), their loads in flight together
@@ -756,8 +861,9 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
         // a write acknowledgement before the next group's loads can be issued.
         __builtin_amdgcn_s_waitcnt(0x0F70);
         fl_store<NT>(a, col, r, row_end - 1, ld2n, live0, live1);
+        panel_out(r);
         g += kStripWaves;
-        if (g < ngroups) fl_load<NT>(a, col, row_begin + 8 * g, row_end - 1, ld2n, live0, live1);
+        if (g < ngroups) { fl_load<NT>(a, col, row_begin + 8 * g, row_end - 1, ld2n, live0, live1); panel_in(row_begin + 8 * g); }
     }
 }
 
@@ -955,7 +1061,56 @@ bool sym_flush_applies(const PoolView& pv, const Pending& pend, const Rank2Tunin
     return pend.symmetric && pv.N >= kSymMinDim && t.rows_per_block == 0;
 }
 
-int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// Column panel: the plan (which landmarks' columns the next flush writes out as rows) and the repair.
+// One thread per filter walks the log slots of the next `nsteps` steps in order and gives the first `slots` distinct
+// landmarks a slot each; the previous plan's entries of lmslot are cleared from plan_list first.  Sequential per filter,
+// a few dozen entries: microseconds.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_panel_plan(int B, int n, const int* __restrict__ lm_idx, int nsteps, int vmax,
+                                                   int slots, short* __restrict__ lmslot, int* __restrict__ plan_list) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    short* ls = lmslot + (size_t)b * n;
+    int* pl = plan_list + (size_t)b * slots;
+    for (int q = 0; q < slots; q++) {
+        const int lm = pl[q];
+        if (lm >= 0 && lm < n) ls[lm] = -1;
+        pl[q] = -1;
+    }
+    int used = 0;
+    for (int t = 0; t < nsteps && used < slots; t++)
+        for (int v = 0; v < vmax && used < slots; v++) {
+            const int lm = lm_idx[((size_t)t * B + b) * vmax + v];
+            if (lm < 0 || lm >= n || ls[lm] >= 0) continue;
+            ls[lm] = (short)used;
+            pl[used++] = lm;
+        }
+}
+
+void launch_panel_plan(const PoolView& pv, const int* lm_idx, int nsteps, int vmax, int slots, short* lmslot, int* plan_list,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_panel_plan, dim3((pv.B + 63) / 64), dim3(64), 0, s, pv.B, pv.n, lm_idx, nsteps, vmax, slots, lmslot,
+                       plan_list);
+}
+
+// matrix columns 1, 2 <- panel rows 1, 2 (the strided writes prediction() skipped while the panel was on).  grid (ceil(N / 256), B)
+__global__ __launch_bounds__(256) void k_panel_repair(double* __restrict__ sigma, const double* __restrict__ colp, int colp_rows,
+                                                      int N, int ld, size_t sigma_stride) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    double* Sg = sigma + (size_t)blockIdx.y * sigma_stride;
+    const double* cp = colp + (size_t)blockIdx.y * colp_rows * ld;
+    Sg[(size_t)k * ld + 1] = cp[(size_t)ld + k];
+    Sg[(size_t)k * ld + 2] = cp[(size_t)2 * ld + k];
+}
+
+void launch_panel_repair(const PoolView& pv, const double* colp, int colp_rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_panel_repair, dim3((pv.N + 255) / 256, pv.B), dim3(256), 0, s, pv.sigma, colp, colp_rows, pv.N, pv.ld,
+                       pv.sigma_stride);
+}
+
+int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s, const PanelIO& panel) {
     if (pend.count <= 0) return 0;
     const size_t pool_bytes = (size_t)pv.B * pv.sigma_stride * sizeof(double);
     const bool nt = t.nontemporal >= 0 ? t.nontemporal != 0 : pool_bytes > ((size_t)192 << 20);
@@ -986,10 +1141,10 @@ int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, 
             const size_t lds = (size_t)pend.count * kStripCols2 * sizeof(double2_t);
             if (nt) hipLaunchKernelGGL((k_flush_strip<true>), grid, dim3(64 * kStripWaves), lds, s, pv.sigma, pend.U,
                                        pend.V, pv.N, pv.ld, pv.sigma_stride, pend.cap, pend.count, rows, strips,
-                                       row_blocks, pv.B);
+                                       row_blocks, pv.B, panel, pv.n);
             else hipLaunchKernelGGL((k_flush_strip<false>), grid, dim3(64 * kStripWaves), lds, s, pv.sigma, pend.U,
                                     pend.V, pv.N, pv.ld, pv.sigma_stride, pend.cap, pend.count, rows, strips,
-                                    row_blocks, pv.B);
+                                    row_blocks, pv.B, panel, pv.n);
             return 1;
         }
     }
@@ -999,7 +1154,7 @@ int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, 
     const int strips = (pv.ld / 2 + 255) / 256, row_blocks = (pv.N + rows - 1) / rows;
     dim3 grid((unsigned)((long long)strips * row_blocks * pv.B));
 #define EKF_FL_ARGS pv.sigma, pend.U, pend.V, pv.N, pv.ld, pv.sigma_stride, pend.cap, pend.count, rows, strips, \
-    row_blocks, pv.B
+    row_blocks, pv.B, panel, pv.n
     if (rows >= 16) {
         if (nt) hipLaunchKernelGGL((k_flush<16, true>), grid, dim3(256), 0, s, EKF_FL_ARGS);
         else hipLaunchKernelGGL((k_flush<16, false>), grid, dim3(256), 0, s, EKF_FL_ARGS);

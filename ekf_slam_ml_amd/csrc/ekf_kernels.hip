@@ -75,6 +75,10 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
     // pend.symmetric == 2 (a delayed known-association run with the mirrored flush): the tiles on and above the diagonal
     // are the covariance until the next flush mirrors them, so columns 1 and 2 are only kept up inside the first
     // diagonal square -- the 16-KB-strided sector per row (most of this kernel's traffic) is not touched
+    // pend.colp (column panel of a delayed known-association run, see Pending): columns 0..2 live as the panel's rows
+    // 0..2 (coalesced) and are kept current THERE; the matrix's own columns 1, 2 are left to the next flush
+    double* __restrict__ cp = pend.colp ? pend.colp + (size_t)b * pend.colp_rows * ld : nullptr;
+    const short* __restrict__ lms = pend.colp ? pend.lmslot + (size_t)b * pv.n : nullptr;
     const int col_rows = pend.symmetric == 2 ? kSymSquare : N;
     // active-set mode: row/column k of a never-corrected landmark is exactly zero against the pose block,
     // so its update a*0 + 0 = 0 is skipped (bit-identical)
@@ -88,7 +92,9 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
             s0[q] = Sg[k];                      // row 0 (coalesced)
             s1[q] = Sg[(size_t)1 * ld + k];
             s2[q] = Sg[(size_t)2 * ld + k];
-            if (k < col_rows) {
+            if (cp) {
+                r0[q] = cp[k]; r1[q] = cp[(size_t)ld + k]; r2[q] = cp[(size_t)2 * ld + k];   // columns 0..2, as rows
+            } else if (k < col_rows) {
                 const double* rowk = Sg + (size_t)k * ld;  // columns 0..2 of row k (one 32-B sector)
                 r0[q] = rowk[0]; r1[q] = rowk[1]; r2[q] = rowk[2];
             }
@@ -129,9 +135,18 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
         const int k = 3 + (int)threadIdx.x + q * kPredictThreads;
         if (live[q]) {
             double* rowk = Sg + (size_t)k * ld;
-            Sg[(size_t)1 * ld + k] = a10 * s0[q] + s1[q];
-            Sg[(size_t)2 * ld + k] = a20 * s0[q] + s2[q];
-            if (k < col_rows) {
+            const double n1 = a10 * s0[q] + s1[q], n2 = a20 * s0[q] + s2[q];
+            Sg[(size_t)1 * ld + k] = n1;
+            Sg[(size_t)2 * ld + k] = n2;
+            if (cp) {
+                cp[(size_t)ld + k] = r0[q] * a10 + r1[q];
+                cp[(size_t)2 * ld + k] = r0[q] * a20 + r2[q];
+                const int sl = lms[(k - 3) >> 1];
+                if (sl >= 0) {   // a planned landmark column: its entries at the rows 1, 2
+                    double* pr = cp + (size_t)(3 + 2 * sl + ((k - 3) & 1)) * ld;
+                    pr[1] = n1; pr[2] = n2;
+                }
+            } else if (k < col_rows) {
                 rowk[1] = r0[q] * a10 + r1[q];
                 rowk[2] = r0[q] * a20 + r2[q];
             }
@@ -142,9 +157,19 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
         const double t0 = Sg[k];
         const double t1 = Sg[(size_t)1 * ld + k];
         const double t2 = Sg[(size_t)2 * ld + k];
-        Sg[(size_t)1 * ld + k] = a10 * t0 + t1;
-        Sg[(size_t)2 * ld + k] = a20 * t0 + t2;
-        if (k < col_rows) {
+        const double n1 = a10 * t0 + t1, n2 = a20 * t0 + t2;
+        Sg[(size_t)1 * ld + k] = n1;
+        Sg[(size_t)2 * ld + k] = n2;
+        if (cp) {
+            const double q0 = cp[k], q1 = cp[(size_t)ld + k], q2 = cp[(size_t)2 * ld + k];
+            cp[(size_t)ld + k] = q0 * a10 + q1;
+            cp[(size_t)2 * ld + k] = q0 * a20 + q2;
+            const int sl = lms[(k - 3) >> 1];
+            if (sl >= 0) {
+                double* pr = cp + (size_t)(3 + 2 * sl + ((k - 3) & 1)) * ld;
+                pr[1] = n1; pr[2] = n2;
+            }
+        } else if (k < col_rows) {
             double* rowk = Sg + (size_t)k * ld;
             const double q0 = rowk[0], q1 = rowk[1], q2 = rowk[2];
             rowk[1] = q0 * a10 + q1;
@@ -180,6 +205,9 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
         Sg[0] += pv.p.q_pose;  // Q = diag(q,q,q,0...) :40-43
         Sg[(size_t)1 * ld + 1] += pv.p.q_pose;
         Sg[(size_t)2 * ld + 2] += pv.p.q_pose;
+        if (cp)   // the pose block, mirrored into the panel (row c of the panel = column c of Sigma)
+            for (int r = 0; r < 3; r++)
+                for (int k = 0; k < 3; k++) cp[(size_t)k * ld + r] = Sg[(size_t)r * ld + k];
     }
 }
 

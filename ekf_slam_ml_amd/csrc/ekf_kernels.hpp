@@ -49,6 +49,26 @@ struct Pending {
     int symmetric;  // 1: the gain step takes Sigma H^T as (H Sigma)^T (see ekf_set_update_mode); 2: and, inside a delayed
                     // known-association run whose flushes mirror (sym_flush_applies), the tiles on and above the diagonal
                     // ARE the covariance between flushes: k_predict leaves columns 1, 2 below the first square alone
+    // Column panel (delayed known-association runs of a pool, ekf_batch_run_known; nullptr = off).  Sigma H^T reads
+    // COLUMNS of Sigma (ekf_slam.cpp:178): entries 16 KB apart, one 64-byte sector fetched per 8 or 16 useful bytes.
+    // The flush, which holds every new entry of Sigma_base in registers anyway, also writes the columns the NEXT
+    // corrections will read as contiguous rows colp[b][row][ld]: rows 0..2 = columns 0, 1, 2; rows 3 + 2s, 4 + 2s =
+    // the two columns of the landmark planned into slot s (lmslot[b][landmark] = s, or -1: that landmark's columns are
+    // gathered from the matrix as before -- the plan is a hint, never a condition of correctness).  While a panel is
+    // on, prediction() keeps the matrix's ROWS 1, 2 and the panel's rows 0..2 current and leaves the matrix's columns
+    // 1, 2 (one sector per row, most of k_predict's traffic) to the next flush, which takes them from the panel.
+    // Same values from another address: bit-identical to the run without a panel.
+    double* colp;
+    const short* lmslot;
+    int colp_rows;   // rows of a filter's panel (3 + 2 x slots)
+};
+// flush <-> panel: `in` (nullable) = the panel that has been on since the last flush (its rows 1, 2 ARE the matrix's
+// columns 1, 2); `out` (nullable) = the panel to write for the landmarks of `lmslot`
+struct PanelIO {
+    const double* in;
+    double* out;
+    const short* lmslot;
+    int rows;
 };
 constexpr int kSymSquare = 32;   // side of the mirrored flush's diagonal squares (its tile rows)
 
@@ -413,7 +433,15 @@ void launch_gain_delayed_pair(const PoolView& pv, const CmdSrc& src, const Pendi
                               hipStream_t s);
 // Sigma_base -= sum_j U[j] V[j]^T for j < pend.count (count even); the caller then resets count to 0.
 // Returns the form taken: 0 plain (k_flush), 1 strip (k_flush_strip).
-int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s);
+int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, hipStream_t s,
+                 const PanelIO& panel = PanelIO{nullptr, nullptr, nullptr, 0});
+// Column panel of a delayed known-association run (Pending::colp).  plan: which landmarks the next corrections of every
+// filter touch -- the log slots lm_idx[t][b][v] of `nsteps` steps from `lm_idx` on, in order, the first `slots` distinct
+// ones; plan_list [B][slots] remembers them so that the next plan can clear lmslot [B][n] again.
+void launch_panel_plan(const PoolView& pv, const int* lm_idx, int nsteps, int vmax, int slots, short* lmslot, int* plan_list,
+                       hipStream_t s);
+// matrix columns 1, 2 <- panel rows 1, 2 (a run that ends on predictions with nothing pending)
+void launch_panel_repair(const PoolView& pv, const double* colp, int colp_rows, hipStream_t s);
 bool sym_flush_applies(const PoolView& pv, const Pending& pend, const Rank2Tuning& t);   // launch_flush would mirror
 void launch_sym_repair(const PoolView& pv, hipStream_t s);
 // top of measurement(): pose snapshot (+ first-call landmark initialisation from init_xy [B][2n])

@@ -278,6 +278,7 @@ struct Pool {
         active_prefix = (f & EKF_FORM_ACTIVE_PREFIX) ? 1 : 0;
         step_fused = (f & EKF_FORM_STEP_FUSED) ? ((f & EKF_FORM_STEP_SPLIT_PASS) ? 1 : 2) : 0;
         delayed_pair = (f & EKF_FORM_DELAYED_PAIR) ? 1 : 0;
+        column_panel = (f & EKF_FORM_COLUMN_PANEL) ? ((f & EKF_FORM_COLUMN_PANEL_ONE_SLOT) ? 2 : 1) : 0;
         tuning.row_packing = (f & EKF_FORM_ROW_PACKING) ? 1 : 0;
         tuning.strip_flush = (f & EKF_FORM_STRIP_FLUSH_ALWAYS) ? 2 : (f & EKF_FORM_STRIP_FLUSH) ? 1 : 0;
         alt_synced = false;
@@ -289,7 +290,50 @@ struct Pool {
         tuning.group_rows = group_rows;
     }
 
-    ekf::Pending pending() const { return ekf::Pending{Uf, Vf, pend_cap, pend_count, pend_symmetric}; }
+    ekf::Pending pending() const {
+        ekf::Pending p{Uf, Vf, pend_cap, pend_count, pend_symmetric};
+        if (panel_active) { p.colp = colp; p.lmslot = lmslot; p.colp_rows = colp_rows(); }
+        return p;
+    }
+
+    // Column panel of delayed known-association runs (ekf_kernels.hpp, Pending::colp; EKF_FORM_COLUMN_PANEL): buffers, and
+    // whether the panel currently holds the columns of the materialised covariance (panel_valid: set by a run whose
+    // closing flush wrote it, cleared by ANY later entry into the handle -- use() -- so a panel never outlives a change
+    // of Sigma that did not go through it).  panel_active: inside ekf_batch_run_known's loop only.
+    double* colp = nullptr;       // [B][3 + 2 slots][ld]
+    short* lmslot = nullptr;      // [B][n]
+    int* plan_list = nullptr;     // [B][slots]
+    int colp_slots = 0;
+    int column_panel = 1;         // 0 off, 1 on, 2 on with a ONE-slot plan (test hook: the gather fallback beside the panel)
+    bool panel_valid = false, panel_active = false;
+    int colp_rows() const { return 3 + 2 * colp_slots; }
+    ekf_status free_panel() {
+        if (colp) HIPC(hipFree(colp));
+        if (lmslot) HIPC(hipFree(lmslot));
+        if (plan_list) HIPC(hipFree(plan_list));
+        colp = nullptr; lmslot = nullptr; plan_list = nullptr; colp_slots = 0;
+        panel_valid = panel_active = false;
+        return EKF_OK;
+    }
+    ekf_status ensure_panel(bool* fresh) {   // *fresh: the buffers were (re)created -- whatever panel was valid is gone
+        int want = column_panel == 2 ? 1 : pend_cap / 2;
+        if (want > 64) want = 64;
+        if (want < 1) want = 1;
+        *fresh = false;
+        if (colp && colp_slots == want) return EKF_OK;
+        *fresh = true;
+        HIPC(hipStreamSynchronize(stream));
+        EKFC(free_panel());
+        colp_slots = want;
+        const size_t np = (size_t)pv.B * colp_rows() * pv.ld, nl = (size_t)pv.B * (pv.n > 0 ? pv.n : 1), nq = (size_t)pv.B * want;
+        HIPC(hipMalloc((void**)&colp, np * sizeof(double)));
+        HIPC(hipMalloc((void**)&lmslot, nl * sizeof(short)));
+        HIPC(hipMalloc((void**)&plan_list, nq * sizeof(int)));
+        HIPC(hipMemsetAsync(colp, 0, np * sizeof(double), stream));       // (pad entries of the rows stay 0)
+        HIPC(hipMemsetAsync(lmslot, 0xFF, nl * sizeof(short), stream));   // -1: no landmark has a slot
+        HIPC(hipMemsetAsync(plan_list, 0xFF, nq * sizeof(int), stream));
+        return EKF_OK;
+    }
 
     ekf_status set_update_mode(int max_pending_corrections, int symmetric_gather) {
         EKFC(use());
@@ -298,6 +342,7 @@ struct Pool {
         HIPC(hipStreamSynchronize(stream));
         for (double** p : {&Uf, &Vf, &state_alt})
             if (*p) { HIPC(hipFree(*p)); *p = nullptr; }
+        EKFC(free_panel());
         pend_cap = 0;
         if (max_pending_corrections <= 0) return EKF_OK;
         int cap = 2 * max_pending_corrections;
@@ -312,10 +357,10 @@ struct Pool {
     }
 
     // fold every pending correction into Sigma_base (no-op in eager mode)
-    ekf_status flush() {
+    ekf_status flush(const ekf::PanelIO& panel = ekf::PanelIO{nullptr, nullptr, nullptr, 0}) {
         if (pend_count > 0) {
             alt_synced = false;
-            form_counts[ekf::launch_flush(pv, pending(), tuning, stream)]++;
+            form_counts[ekf::launch_flush(pv, pending(), tuning, stream, panel)]++;
             HIPC(hipGetLastError());
             pend_count = 0;
         }
@@ -330,6 +375,7 @@ struct Pool {
     ekf_status correct_pair(const ekf::CmdSrc& src) {
         ekf::launch_gain_delayed_pair(pv, src, pending(), state_alt, stream);
         form_counts[2]++;
+        if (panel_active) form_counts[7]++;
         std::swap(pv.state, state_alt);
         pend_count += 4;
         return EKF_OK;
@@ -339,6 +385,7 @@ struct Pool {
             // (a measurement that data_association() drops appends a zero pair: the state buffers swap either way)
             if (pend_count + 2 > pend_cap) EKFC(flush());
             ekf::launch_gain_delayed(pv, src, pending(), state_alt, stream);
+            if (panel_active) form_counts[7]++;
             std::swap(pv.state, state_alt);
             pend_count += 2;
             return EKF_OK;
@@ -419,6 +466,7 @@ struct Pool {
     ekf_status use(bool settle = true) {
         HIPC(hipSetDevice(device));
         EKFC(check_device());
+        panel_valid = panel_active = false;   // (see colp: whoever enters the handle may change Sigma)
         if (settle && pred_pending) {
             pred_pending = false;
             launch_predict_now(pred_dth, pred_dx);
@@ -501,7 +549,8 @@ struct Pool {
                         pv.touch_count, scores, meas_dev, assoc_block,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, sigma_alt, state_fz, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
-                        phase_trace, terms2, scores2, blk_cache, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred};
+                        phase_trace, terms2, scores2, blk_cache, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred,
+                        colp, lmslot, plan_list};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();

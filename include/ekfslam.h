@@ -151,7 +151,15 @@ typedef enum {
     EKF_FORM_STRIP_FLUSH = 1u << 8,
     /* test hook: the strip-form flush on pools of any size, for any count <= 80 vectors. */
     EKF_FORM_STRIP_FLUSH_ALWAYS = 1u << 9,
-    EKF_FORMS_DEFAULT = (1u << 9) - 1
+    /* delayed mode, ekf_batch_run_known: the flush also writes the COLUMNS of Sigma that the next corrections' K = Sigma H^T
+     * S^-1 (ekf_slam.cpp:178) will read -- columns 0..2 and the two columns of every landmark in the next corrections of
+     * the device-resident log -- as contiguous rows of a column panel, the gain kernels read them coalesced instead of as
+     * 16-KB-strided sectors, and prediction() keeps columns 0..2 current in the panel (coalesced) instead of in the matrix.
+     * Same values from another address: bit-identical.  Off: columns are gathered from the matrix. */
+    EKF_FORM_COLUMN_PANEL = 1u << 10,
+    /* test hook: the panel plans ONE landmark per flush period, so panel rows and matrix gathers are mixed in one launch. */
+    EKF_FORM_COLUMN_PANEL_ONE_SLOT = 1u << 11,
+    EKF_FORMS_DEFAULT = ((1u << 9) - 1) | (1u << 10)
 } ekf_form;
 ekf_status ekf_set_forms(ekf_handle h, unsigned forms);
 ekf_status ekf_get_forms(ekf_handle h, unsigned* forms);
@@ -160,7 +168,7 @@ ekf_status ekf_batch_get_forms(ekf_batch_handle hb, unsigned* forms);
 /* Test hook: covariance passes of each form this pool has launched since it was created --
  * counts[0] plain flush, [1] strip-form flush, [2] paired delayed gain launches, [3] call-fused passes,
  * [4] per-landmark rank-2 streams, [5] step-fused launches with a separate pass, [6] mirrored flushes (symmetric
- * option of ekf_set_update_mode), [7] reserved (0). */
+ * option of ekf_set_update_mode), [7] delayed gain launches that read the column panel (EKF_FORM_COLUMN_PANEL). */
 ekf_status ekf_batch_form_counts(ekf_batch_handle hb, long long counts[8]);
 
 /* Active-set covariance update (opt-in, default 0; reported separately from the dense contract path):

@@ -362,3 +362,110 @@ def test_delayed_at_the_million_steps_configuration(hip, oracle, symmetric):
             o.measurement_compact(log.init_xy[b], log.lm_idx[t, b], log.z_xy[t, b])
         assert_parity(bt.state(b), bt.cov(b), o.state, o.cov, FP64_TOL, f"filter {b}")
     bt.close()
+
+
+@pytest.mark.parametrize("B,n,k,vmax,strip,blind_tail", [
+    (5, 130, 8, 2, False, 0),     # pairs, plain flush, several flush periods
+    (4, 130, 8, 2, True, 0),      # ... strip-form flush writes / reads the panel
+    (3, 200, 5, 3, False, 2),     # pair + trailing single launch per step, flushes inside steps, run ends on predictions
+    (3, 140, 16, 1, True, 3),     # single launches only (k_gain_delayed), strip flush, blind tail
+    (2, 333, 3, 5, False, 0),     # more landmarks per period than k: some planned, flush boundaries everywhere
+    (6, 1000, 32, 2, False, 0),   # the bench shape (n = 1000, k = 32, V = 2)
+    (2, 127, 4, 4, True, 1),      # N = 257: just above the panel's minimum dimension
+])
+def test_column_panel_is_bit_identical(hip, oracle, B, n, k, vmax, strip, blind_tail):
+    """EKF_FORM_COLUMN_PANEL (delayed known-association runs): the flush writes columns 0..2 and the columns of the
+    landmarks of the next corrections as contiguous panel rows, the gain kernels read Sigma H^T's operands (ekf_slam.cpp:178)
+    from there, prediction() keeps columns 0..2 in the panel and leaves the matrix's to the next flush.  Same values from
+    another address: state and covariance must be BIT-identical to the run without the panel -- with the plan holding every
+    landmark of a period, with the one-slot plan (panel rows and matrix gathers mixed in one launch), across run boundaries
+    that hand the panel over, across boundaries that drop it (a getter in between), and when a run ends on predictions with
+    nothing pending (the repair).  One filter against the CPU checker at 1e-9."""
+    T = 19
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=4100 + n + k, half_extent=3.0, min_spacing=0.1,
+                          max_visible_dis=1.1 if vmax > 2 else 1e9, vmax=vmax, v_cmd=0.8, w_cmd=0.5)
+    log = synth.make_known_log(cfg)
+    lm = log.lm_idx.copy()
+    if blind_tail:
+        lm[-blind_tail:] = -1          # the run ends on predictions: nothing pending, matrix columns 1, 2 behind
+    lm[7, 0] = -1                      # one filter sits a step out
+    base = hip.FORMS_DEFAULT | (hip.FORM_STRIP_FLUSH_ALWAYS if strip else 0)
+    variants = {"panel": base, "one_slot": base | hip.FORM_COLUMN_PANEL_ONE_SLOT, "off": base & ~hip.FORM_COLUMN_PANEL}
+    outs, counts = {}, {}
+    for name, forms in variants.items():
+        for cuts in ((T,), (4, 5, 11, T)):          # one run; four consecutive runs (the panel is handed over)
+            bt = hip.BatchEKF(B, n)
+            bt.set_forms(forms)
+            bt.set_update_mode(k)
+            bt.upload_known_log(log.twist, lm, log.z_xy, log.init_xy)
+            t0 = 0
+            for t1 in cuts:
+                bt.run_known(t0, t1)
+                t0 = t1
+            counts[name, cuts] = bt.form_counts()
+            outs[name, cuts] = ([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)])
+            bt.close()
+    # a getter between two runs drops the panel: the next run starts without one (still the same numbers)
+    bt = hip.BatchEKF(B, n)
+    bt.set_forms(variants["panel"])
+    bt.set_update_mode(k)
+    bt.upload_known_log(log.twist, lm, log.z_xy, log.init_xy)
+    bt.run_known(0, 9)
+    mid = bt.state(0)
+    bt.run_known(9, T)
+    outs["panel", "getter"] = ([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)])
+    bt.close()
+    # (where the flushes fall changes the delayed mode's rounding -- its reconstruction and its flush contract their
+    # multiply-adds -- so every variant is compared with the panel-less run over the SAME run boundaries)
+    bt = hip.BatchEKF(B, n)
+    bt.set_forms(variants["off"])
+    bt.set_update_mode(k)
+    bt.upload_known_log(log.twist, lm, log.z_xy, log.init_xy)
+    bt.run_known(0, 9); bt.run_known(9, T)
+    outs["off", "getter"] = ([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)])
+    bt.close()
+    for (name, cuts), (st, cv) in outs.items():
+        ref = outs["off", cuts]
+        for b in range(B):
+            assert np.array_equal(st[b], ref[0][b]) and np.array_equal(cv[b], ref[1][b]), f"{name} {cuts}, filter {b}"
+    assert counts["off", (T,)]["gain_from_panel"] == 0
+    for name in ("panel", "one_slot"):
+        c1, c4 = counts[name, (T,)], counts[name, (4, 5, 11, T)]
+        assert c4["gain_from_panel"] > 0, c4          # a closing flush hands the panel to the next run
+        if c1["flush_plain"] + c1["flush_strip"] >= 2:  # (a single run has a panel from its first flush on)
+            assert c1["gain_from_panel"] > 0, c1
+        assert c4["gain_from_panel"] >= c1["gain_from_panel"]
+    o = oracle.OracleEKF(n, oracle.STRUCTURED)
+    b = B - 1
+    for t in range(T):
+        o.prediction(*log.twist[t, b]); o.measurement_compact(log.init_xy[b], lm[t, b], log.z_xy[t, b])
+    assert_parity(outs["panel", (T,)][0][b], outs["panel", (T,)][1][b], o.state, o.cov, FP64_TOL, "panel vs checker")
+    assert mid.shape == (3 + 2 * n,)
+
+
+def test_column_panel_at_the_million_steps_configuration(hip):
+    """bench.py's delayed leg as the driver runs it: a warm-up run, then the timed run of whole flush periods on the same
+    handle with nothing in between -- the warm-up's closing flush writes the panel for the timed run's first corrections,
+    so EVERY gain launch of the timed run reads the panel (asserted), and the result is bit-identical to the run with the
+    panel off (B = 128 so that the strip-form flush is taken by itself, as at B = 4096)."""
+    B, n, k, W, K = 128, 1000, 32, 5, 32
+    T = 1 + W + K
+    log = synth.make_known_log(synth.config5(filters=B, steps=T, n=n))
+    res = []
+    for forms in (hip.FORMS_DEFAULT, hip.FORMS_DEFAULT & ~hip.FORM_COLUMN_PANEL):
+        bt = hip.BatchEKF(B, n)
+        bt.set_forms(forms)
+        bt.set_update_mode(k)
+        bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+        bt.run_known(0, 1 + W)
+        before = bt.form_counts()
+        bt.run_known(1 + W, T)
+        after = bt.form_counts()
+        res.append((after["gain_from_panel"] - before["gain_from_panel"], after["gain_pairs"] - before["gain_pairs"],
+                    after["flush_strip"] - before["flush_strip"], [bt.state(b) for b in (0, 77, B - 1)], bt.cov(B - 1)))
+        bt.close()
+    assert res[0][0] == res[0][1] == K and res[0][2] == 2, res[0][:3]     # every timed gain launch read the panel
+    assert res[1][0] == 0 and res[1][1] == K
+    for a, b in zip(res[0][3], res[1][3]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[0][4], res[1][4])
