@@ -18,6 +18,23 @@ namespace ekf {
 
 constexpr int kMaxPending = 128;
 
+// 1-D grid of B x parts workgroups, XCD-aware (speed only): workgroup ids are dealt round-robin to the 8 XCDs, each with its
+// own L2.  The `parts` workgroups of one filter all gather the same pending-factor entries at the correction's core
+// indices (7 columns x count x 2 values, one sector each): a filter is given to ONE XCD so that three of four find them in
+// its L2 (PMC, profiles/r04: dealt over four XCDs these gathers were 14 % of the gain kernel's fetched bytes).
+__device__ __forceinline__ void xcd_decode(int id, int parts, int B, int& b, int& part) {
+    const int full = (B / 8) * 8 * parts;
+    if (id < full) {
+        const int xcd = id & 7, slot = id >> 3;
+        b = (slot / parts) * 8 + xcd;
+        part = slot % parts;
+    } else {   // the last B % 8 filters: plain order
+        const int rest = id - full;
+        b = (B / 8) * 8 + rest / parts;
+        part = rest % parts;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // One landmark correction in delayed mode: ekf_slam.cpp:137-187 without the covariance stream.
 // grid (ceil(ld/512), B).  Reads: state (in), Sigma_base, U/V rows [0, count); writes: U/V rows
@@ -29,7 +46,8 @@ constexpr int kMaxPending = 128;
 template <bool SYM>
 __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, Pending pend,
                                                       double* __restrict__ state_out) {
-    const int b = blockIdx.y;
+    int b, part;
+    xcd_decode(blockIdx.x, (pv.ld / 2 + 255) / 256, pv.B, b, part);
     const int tid = threadIdx.x;
     const int N = pv.N, ld = pv.ld;
     const int rc = pend.count;
@@ -41,7 +59,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
     __shared__ double sh_nu[2];
 
     // a lane owns the two consecutive indices r, r+1 (16-B accesses); a workgroup covers 512 indices
-    const int r = 2 * (blockIdx.x * 256 + tid);
+    const int r = 2 * (part * 256 + tid);
     const double* st = pv.state + (size_t)b * ld;
     double* so = state_out + (size_t)b * ld;
     double* Ub = pend.U + (size_t)b * pend.cap * ld;
@@ -75,7 +93,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
             *reinterpret_cast<double2_t*>(Vb + (size_t)rc * ld + r) = zero2;
             *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + 1) * ld + r) = zero2;
         }
-        if (blockIdx.x == 0 && tid == 0) pv.rec[b].active = 0;
+        if (part == 0 && tid == 0) pv.rec[b].active = 0;
         return;
     }
 
@@ -110,7 +128,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
             const double* sn = pv.snap + (size_t)b * 4;
             theta = sn[0]; x = sn[1]; y = sn[2];
         }
-        if (src.write_snap && blockIdx.x == 0) {
+        if (src.write_snap && part == 0) {
             double* sn = pv.snap + (size_t)b * 4;
             sn[0] = theta; sn[1] = x; sn[2] = y;
         }
@@ -126,7 +144,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
         sh_Si[0] = Si[0][0]; sh_Si[1] = Si[0][1]; sh_Si[2] = Si[1][0]; sh_Si[3] = Si[1][1];
         sh_nu[0] = m.z0 - m.zh0;                   // :182
         sh_nu[1] = normalize_angle(m.z1 - m.zh1);  // :183
-        if (blockIdx.x == 0) {
+        if (part == 0) {
             CorrRec rcd;
             rcd.nu0 = sh_nu[0]; rcd.nu1 = sh_nu[1]; rcd.active = 1; rcd.lm = lm; rcd.n_active = 0; rcd.pad = 0;
             pv.rec[b] = rcd;
@@ -245,7 +263,8 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
 template <bool SYM>
 __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc src, Pending pend,
                                                            double* __restrict__ state_out) {
-    const int b = blockIdx.y;
+    int b, part;
+    xcd_decode(blockIdx.x, (pv.ld / 2 + 255) / 256, pv.B, b, part);
     const int tid = threadIdx.x;
     const int N = pv.N, ld = pv.ld;
     const int rc = pend.count;
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     __shared__ double sh_H[2][10], sh_Si[2][4], sh_nu[2][2];
     __shared__ double sh_K1B[5][2], sh_G1B[2][5]; // K1 / G1 at the five indices of landmark 2
 
-    const int r = 2 * (blockIdx.x * 256 + tid);
+    const int r = 2 * (part * 256 + tid);
     const double* st = pv.state + (size_t)b * ld;
     double* so = state_out + (size_t)b * ld;
     double* Ub = pend.U + (size_t)b * pend.cap * ld;
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
                 *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + q) * ld + r) = zero2;
             }
         }
-        if (blockIdx.x == 0 && tid == 0) pv.rec[b].active = 0;
+        if (part == 0 && tid == 0) pv.rec[b].active = 0;
         return;
     }
     const bool two_corr = lm2 >= 0;
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
             sh_nu[1][0] = m2.z0 - m2.zh0;
             sh_nu[1][1] = normalize_angle(m2.z1 - m2.zh1);
         }
-        if (blockIdx.x == 0) {
+        if (part == 0) {
             CorrRec rcd;
             rcd.nu0 = two_corr ? sh_nu[1][0] : nu0; rcd.nu1 = two_corr ? sh_nu[1][1] : nu1;
             rcd.active = 1; rcd.lm = two_corr ? lm2 : lm1; rcd.n_active = 0; rcd.pad = 0;
@@ -1012,14 +1031,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_flush_sym(double* __restrict__ s
 
 void launch_gain_delayed(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
                          hipStream_t s) {
-    const dim3 grid((pv.ld / 2 + 255) / 256, pv.B);
+    const dim3 grid((unsigned)((long long)((pv.ld / 2 + 255) / 256) * pv.B));
     if (pend.symmetric) hipLaunchKernelGGL(k_gain_delayed<true>, grid, dim3(256), 0, s, pv, src, pend, state_out);
     else hipLaunchKernelGGL(k_gain_delayed<false>, grid, dim3(256), 0, s, pv, src, pend, state_out);
 }
 
 void launch_gain_delayed_pair(const PoolView& pv, const CmdSrc& src, const Pending& pend, double* state_out,
                               hipStream_t s) {
-    const dim3 grid((pv.ld / 2 + 255) / 256, pv.B);
+    const dim3 grid((unsigned)((long long)((pv.ld / 2 + 255) / 256) * pv.B));
     if (pend.symmetric) hipLaunchKernelGGL(k_gain_delayed_pair<true>, grid, dim3(256), 0, s, pv, src, pend, state_out);
     else hipLaunchKernelGGL(k_gain_delayed_pair<false>, grid, dim3(256), 0, s, pv, src, pend, state_out);
 }
