@@ -47,7 +47,7 @@ SYMBOLS = [
 ]
 
 # ekf_form (include/ekfslam.h): launch structures the library may take where they apply; all exact forms are bit-identical
-FORM_SMALL_MAP, FORM_FUSED_CORRECTION, FORM_CALL_FUSED, FORM_ACTIVE_PREFIX = 1 << 0, 1 << 1, 1 << 2, 1 << 3
+FORM_SMALL_MAP, FORM_CALL_FUSED, FORM_ACTIVE_PREFIX = 1 << 0, 1 << 2, 1 << 3   # (1 << 1: retired, ignored)
 FORM_STEP_FUSED, FORM_STEP_SPLIT_PASS, FORM_DELAYED_PAIR, FORM_ROW_PACKING = 1 << 4, 1 << 5, 1 << 6, 1 << 7
 FORM_STRIP_FLUSH, FORM_STRIP_FLUSH_ALWAYS = 1 << 8, 1 << 9
 FORM_COLUMN_PANEL, FORM_COLUMN_PANEL_ONE_SLOT = 1 << 10, 1 << 11
@@ -356,9 +356,6 @@ class EKF_SLAM:
 
     def set_active_prefix(self, enable=True):
         self._form(FORM_ACTIVE_PREFIX, enable)
-
-    def set_fused_correction(self, enable=True):
-        self._form(FORM_FUSED_CORRECTION, enable)
 
     def set_call_fused(self, enable=True):
         """measurement() as two launches per call (factor panels + one pass over Sigma); default on, bit-identical"""

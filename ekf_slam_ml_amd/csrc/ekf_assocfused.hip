@@ -11,7 +11,7 @@
 // k_assoc_reading every workgroup repeats the decision (a reduction over M scores), then either builds the gain for a slice
 //                 of 256 state indices or scores the NEXT reading for 256 landmarks -- see the kernel.
 // Same operations in the same order as k_maha + k_assoc_decide + k_gain + k_rank2 -> decisions, state and covariance
-// bit-identical (tests/test_gpu_fused.py, tests/test_gpu_callfused.py).
+// bit-identical (tests/test_gpu_forms.py, tests/test_gpu_callfused.py).
 #include "ekf_kernels.hpp"
 
 #include <climits>

@@ -104,7 +104,6 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     if (P.small_path && P.pend_cap == 0 && P.pv.N <= ekf::small_max_dim() && n > 0) {
         // small map (the reference runs n = 20): the whole call -- and the prediction() before it -- in one
         // LDS-resident launch whose inputs travel by value in the kernel arguments (no staging, no copy)
-        P.alt_synced = false;
         ekf::SmallInline in;
         std::memcpy(in.sensor, sensor_xy, sizeof(double) * 2 * n);
         std::memcpy(in.visible, visible, (size_t)n);
@@ -191,16 +190,6 @@ ekf_status ekf_measure_known(ekf_handle h, const double* sensor_xy, const uint8_
     return checked_launch();
 }
 
-// smallest active dimension for which data_association() of a single filter takes the once-per-call form (measured:
-// tools/assoc_bench.py); EKF_ASSOC_MIN_DIM overrides it for that measurement
-static int assoc_call_fused_min_dim() {
-    static const int v = [] {
-        const char* e = std::getenv("EKF_ASSOC_MIN_DIM");
-        return e ? std::atoi(e) : 1400;
-    }();
-    return v;
-}
-
 // Tail of every data_association() form: one synchronising read-back of the association record and the
 // decisions, then the caller's known_list (:323) and the host-side bounds are brought up to date.
 static ekf_status associate_finish(Pool& P, int known_count, int J, uint8_t* known, int* assoc_out) {
@@ -258,7 +247,6 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     P.pub_sent = false;
     if (!delayed && P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && J <= ekf::kSmallInlineJ) {
         // small map: the whole call (and the prediction() before it) in one LDS-resident launch, measurements by value
-        P.alt_synced = false;
         ekf::SmallInlineMeas in;
         std::memcpy(in.xy, meas_xy, sizeof(double) * 2 * J);
         ekf::launch_small_associate_inline(P.pv, in, J, known_count, P.assoc_out_dev, P.pred_pending, P.pred_dth, P.pred_dx,
@@ -267,8 +255,8 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         EKFC(checked_launch());
         return associate_finish(P, known_count, J, known, assoc_out);
     }
-    // The two-launch path per reading (k_maha + k_associate_fused) takes its readings BY VALUE in the kernel arguments;
-    // every other path reads them from the device: staged on first need (one host-to-device copy per call, ~5 us).
+    // The call-fused forms take their readings BY VALUE in the kernel arguments; every other path reads them from the device:
+    // staged on first need (one host-to-device copy per call, ~5 us).
     bool staged = false;
     auto need_dev = [&]() -> ekf_status {
         if (!staged) EKFC(P.upload(P.meas_dev, meas_xy, sizeof(double) * 2 * J));
@@ -278,7 +266,6 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
     if (!delayed && P.small_path && P.pv.N <= ekf::small_max_dim() && n > 0 && n <= 128) {
         // small map: scores, decisions and corrections of all J measurements in one LDS-resident launch
         EKFC(need_dev());
-        P.alt_synced = false;
         ekf::launch_small_associate(P.pv, P.meas_dev, J, known_count, P.assoc_out_dev, P.pred_pending, P.pred_dth,
                                     P.pred_dx, P.stream);
         P.pred_pending = false;
@@ -297,7 +284,6 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         const int Nb = 3 + 2 * m;
         if (!delayed && P.small_path && P.active_prefix && n > 0 && Nb <= ekf::small_max_dim()) {
             EKFC(need_dev());
-            P.alt_synced = false;
             ekf::PoolView pva = P.pv;
             pva.N = Nb;
             ekf::launch_pool_associate(pva, P.meas_dev, nullptr, J, 3 + 2 * P.touched_hwm, P.assoc_out_dev, nullptr, P.stream);
@@ -329,7 +315,6 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
         if (P.touched_hwm > carried) carried = P.touched_hwm;
         if (!delayed && P.pv.B == 1 && P.call_fused_ok() && carried <= ekf::assoc_call_capacity()) {
             EKFC(P.ensure_callfused());
-            P.alt_synced = false;
             for (int j0 = 0; j0 < J; j0 += ekf::kCallV) {
                 const int jc = J - j0 < ekf::kCallV ? J - j0 : ekf::kCallV;
                 ekf::AssocCallArgs ca{};
@@ -355,12 +340,13 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
             return associate_finish(P, known_count, J, known, assoc_out);
         }
     }
-    // Big discovered prefixes (>= 1400: from ~15 MB of covariance per reading): scores / decision + gain against the stored
-    // covariance minus the call's pending pairs (two small launches per reading) and ONE pass over Sigma per call (per 8
-    // readings) -- ekf_assocfused.hip; bit-identical.  Measured at n = 1000, known = 1000 (tools/assoc_bench.py):
-    // 24.5 us per reading against 26.6 us for scores + one streaming launch per reading; below that size the streaming
-    // launch is cheap and two launches per reading win (configs[2]'s discovery run: 12.7 k vs 10.5 k steps/s).
-    if (!delayed && P.pv.B == 1 && P.call_fused_ok() && active_dim(0) >= assoc_call_fused_min_dim()) {
+    // Discovered maps beyond one workgroup: ONE launch per reading -- decision + gain against the stored covariance minus the
+    // call's pending pairs, and the next reading's scores -- and ONE pass over Sigma per call (per 8 readings);
+    // ekf_assocfused.hip, bit-identical.  (Round 3 took this form from an active dimension of 1400 on and an out-of-place
+    // correction launch per reading below it; measured in round 4, tools/forms_ab.py: 89-92 us per 8-reading call at
+    // n = 460 ... 690 against 122-138 us -- the per-reading form wins wherever the one-workgroup form ends, and the
+    // out-of-place form with its second N x N buffer is gone.)
+    if (!delayed && P.pv.B == 1 && P.call_fused_ok()) {
         EKFC(P.ensure_callfused());
         if (!P.terms) EKFC(P.dalloc(&P.terms, (size_t)(n > 0 ? n : 1) * 16));
         if (!P.terms2) {
@@ -368,7 +354,6 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
             EKFC(P.dalloc(&P.scores2, (size_t)(n > 0 ? n : 1)));
         }
         EKFC(P.ensure_blk_cache());   // every landmark's 5 x 5 block, kept current from reading to reading
-        P.alt_synced = false;
         auto m_bound = [&](int j) { return known_count + j < n ? known_count + j : n; };   // known count in front of reading j
         for (int j0 = 0; j0 < J; j0 += ekf::kCallV) {
             const int jc = J - j0 < ekf::kCallV ? J - j0 : ekf::kCallV;
@@ -410,23 +395,6 @@ ekf_status ekf_associate(ekf_handle h, const double* meas_xy, int J, uint8_t* kn
             int m = known_count + j + 1 < n ? known_count + j + 1 : n;
             if (P.touched_hwm > m) m = P.touched_hwm;
             active_N = 3 + 2 * m;
-        }
-        if (P.fused_ok()) {  // two launches per measurement: scores (+ correction terms), then decision + correction
-            EKFC(P.ensure_alt());
-            ekf::MeasSrc msf{nullptr, 2, nullptr, 0, P.terms, meas_xy[2 * j], meas_xy[2 * j + 1], 1};
-            EKFC(P.prof_begin(1));
-            ekf::launch_maha(P.pv, msf, P.scores, -1, known_count + j < n ? known_count + j : n, P.stream);
-            EKFC(P.prof_end());
-            ekf::PoolView view = P.pv;
-            if (active_N > 0 && active_N < P.pv.N) view.N = active_N;
-            EKFC(P.prof_begin(0));
-            ekf::launch_associate_fused(view, msf, P.scores, P.assoc_alt, P.assoc_out_dev + j, P.sigma_alt, P.state_fz,
-                                        P.stream);
-            EKFC(P.prof_end());
-            std::swap(P.pv.sigma, P.sigma_alt);
-            std::swap(P.pv.state, P.state_fz);
-            std::swap(P.pv.assoc, P.assoc_alt);
-            continue;
         }
         EKFC(need_dev());
         const ekf::MeasSrc ms{mj, 2, nullptr, 0};

@@ -136,7 +136,6 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
     EKFC(P.use());
     const int B = P.pv.B, vmax = P.vmax;
     P.touched_hwm = P.pv.n;  // a known log corrects arbitrary indices: no discovered-prefix structure afterwards
-    P.alt_synced = false;
     size_t launches = 0;
     long long corrections = 0;
     for (int t = t_begin; t < t_end; t++)
@@ -360,7 +359,6 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
     const bool delayed = P.pend_cap > 0 && P.step_fused && jmax > 0 && jmax <= ekf::kCallV && 2 * jmax <= P.pend_cap &&
                          P.pend_cap / 2 <= ekf::step_pending_pairs_max();
     if (!delayed) EKFC(P.flush());
-    P.alt_synced = false;
     P.dev_known_count = -1;
     size_t launches = 0;
     for (int t = t_begin; t < t_end; t++) {

@@ -686,13 +686,12 @@ __global__ void k_touch_all(PoolView pv) {
 // Mahalanobis scores, calculate_maha_dis() ekf_slam.cpp:217-276: ONE LANDMARK PER WAVEFRONT.
 // 25 lanes fetch the 5x5 sub-block Sigma[c5,c5] in one go; H*Sigma*H^T is folded with wave
 // shuffles in the CPU restatement's summation order; the innovation bearing is NOT wrapped (:269).
-// grid (ceil(M/4), B), 4 waves per workgroup; M = host bound of the known count (n without one).  With
-// ms.terms the wave also leaves H, S^-1 and nu of its landmark for the correction of the winner.
+// grid (ceil(M/4), B), 4 waves per workgroup; M = host bound of the known count (n without one).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_maha(PoolView pv, MeasSrc ms, double* scores, int m_override, Pending pend) {
     const int b = blockIdx.y;
     if (ms.count && ms.j >= ms.count[b]) return;  // this filter has no measurement in this slot
-    const double meas[2] = {ms.by_value ? ms.vx : ms.xy[(size_t)b * ms.stride], ms.by_value ? ms.vy : ms.xy[(size_t)b * ms.stride + 1]};
+    const double meas[2] = {ms.xy[(size_t)b * ms.stride], ms.xy[(size_t)b * ms.stride + 1]};
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int i = blockIdx.x * 4 + wave;
     const int M = m_override >= 0 ? m_override : pv.assoc[b].known_count;
@@ -744,13 +743,6 @@ __global__ __launch_bounds__(256) void k_maha(PoolView pv, MeasSrc ms, double* s
     const double t1 = v0 * Si[0][1] + v1 * Si[1][1];
     if (lane == 0) {
         scores[(size_t)b * pv.n + i] = t0 * v0 + t1 * v1;
-        if (ms.terms) {  // what the correction of landmark i would need (same pose, same Sigma: :331-381)
-            double* tr = ms.terms + ((size_t)b * pv.n + i) * 16;
-#pragma unroll
-            for (int k = 0; k < 5; k++) { tr[k] = m.H[0][k]; tr[5 + k] = m.H[1][k]; }
-            tr[10] = Si[0][0]; tr[11] = Si[0][1]; tr[12] = Si[1][0]; tr[13] = Si[1][1];
-            tr[14] = v0; tr[15] = v1;
-        }
     }
 }
 

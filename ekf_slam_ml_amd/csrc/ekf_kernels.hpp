@@ -119,12 +119,6 @@ struct MeasSrc {
     int stride;
     const int* count;   // nullable: filter b takes part in slot j iff j < count[b]
     int j;
-    double* terms;      // nullable, single filter: k_maha keeps {H[2][5], S^-1[2][2], nu0, nu1 (unwrapped)} of every
-                        // scored landmark here ([n][16]) so that the correction of the winner need not rebuild them
-    // by_value != 0 (single filter): the reading travels in the kernel arguments (vx, vy) -- no staging copy in front of
-    // the call; xy is not read
-    double vx, vy;
-    int by_value;
 };
 
 struct PoolView {
@@ -458,13 +452,6 @@ void rank2_variant(const PoolView& pv, const Rank2Tuning& t, int* u, int* nontem
 void launch_rank2_active(const PoolView& pv, const Rank2Tuning& t, int max_touched, hipStream_t s);
 void launch_touch_all(const PoolView& pv, hipStream_t s);  // marks every landmark touched (after set_cov)
 // data_association(): scores for landmarks [0, known_count) of every filter, one landmark per wavefront
-// data_association() of ONE measurement after its scores: gate decision, landmark initialisation and the whole
-// correction in one launch, out of place (ekf_fused.hip).  Reads pv.assoc (known_count), writes assoc_next.
-void launch_associate_fused(const PoolView& pv, const MeasSrc& ms, const double* scores, AssocRec* assoc_next,
-                            int* assoc_out_j, double* sigma_next, double* state_next, hipStream_t s);
-// gain + state + covariance of one correction in one launch, OUT OF PLACE into (sigma_next, state_next)
-// (ekf_fused.hip); the caller swaps the buffers afterwards
-void launch_correct_fused(const PoolView& pv, const CmdSrc& src, double* sigma_next, double* state_next, hipStream_t s);
 // parity hook of normalize_angle (a8): out[i] = normalize_angle(in[i])
 void launch_normalize_angles(const double* in, int count, double* out, hipStream_t s);
 // m_bound >= 0: host-side upper bound of every filter's known_count (sizes the grid)

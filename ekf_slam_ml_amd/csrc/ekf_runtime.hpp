@@ -150,13 +150,8 @@ struct Pool {
     int touch_bound_base = 0;                 // touched_bound when that log arrived (filters may not be fresh)
     unsigned char* visible_dev = nullptr;  // [n] (single filter)
 
-    // fused single-launch correction (single filter): the second covariance / state buffer it writes into
-    int fused = 1;
-    double* sigma_alt = nullptr;
-    double* state_fz = nullptr;
-    bool alt_synced = false;  // sigma_alt equals sigma outside the region the next fused correction rewrites
     ekf::AssocRec* assoc_alt = nullptr;  // "next" association record of the fused data_association() step
-    double* terms = nullptr;             // [n][16] correction terms k_maha leaves for the winner
+    double* terms = nullptr;             // one launch per reading (ekf_assocfused.hip): [n][16] terms of the scored landmarks
     double* terms2 = nullptr;            // one launch per reading (ekf_assocfused.hip): terms / scores of the NEXT reading
     double* scores2 = nullptr;
 
@@ -234,7 +229,6 @@ struct Pool {
     }
     // corrections [.., ..) of one call for every filter: factor panels, state, then the streaming pass
     ekf_status call_fused_pass(const ekf::CallSrc& src, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
-        alt_synced = false;
         ekf::launch_call_factors(pv, src, cf_U, cf_V, cf_cnt, cf_state, stream);
         std::swap(pv.state, cf_state);
         if (ev0) HIPC(hipEventRecord(ev0, stream));
@@ -246,25 +240,6 @@ struct Pool {
         return EKF_OK;
     }
 
-    bool fused_ok() const { return fused && pv.B == 1 && pend_cap == 0 && !active_set; }
-    ekf_status ensure_alt() {
-        if (!sigma_alt) {
-            EKFC(dalloc(&sigma_alt, (size_t)pv.B * pv.sigma_stride));
-            EKFC(dalloc(&state_fz, (size_t)pv.B * pv.ld));
-            if (!assoc_alt) EKFC(dalloc(&assoc_alt, (size_t)pv.B));
-            if (!terms) EKFC(dalloc(&terms, (size_t)pv.B * (pv.n > 0 ? pv.n : 1) * 16));
-            alt_synced = false;
-        }
-        if (!alt_synced) {
-            // Both buffers must agree wherever a (prefix-confined) correction does not write.  Anything that
-            // rewrites Sigma in place outside this path clears alt_synced; prediction() needs no copy -- beyond
-            // the discovered prefix it maps zeros to zeros, inside it the next fused correction rewrites all.
-            HIPC(hipMemcpyAsync(sigma_alt, pv.sigma, sizeof(double) * pv.B * pv.sigma_stride, hipMemcpyDeviceToDevice, stream));
-            alt_synced = true;
-        }
-        return EKF_OK;
-    }
-
     // execution forms (ekf_set_forms): which launch structures may be taken where they apply
     unsigned forms = EKF_FORMS_DEFAULT;
     long long form_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ekf_batch_form_counts
@@ -273,7 +248,6 @@ struct Pool {
         EKFC(use());  // (a prediction deferred under the old setting happens now)
         forms = f;
         small_path = (f & EKF_FORM_SMALL_MAP) ? 1 : 0;
-        fused = (f & EKF_FORM_FUSED_CORRECTION) ? 1 : 0;
         call_fused = (f & EKF_FORM_CALL_FUSED) ? 1 : 0;
         active_prefix = (f & EKF_FORM_ACTIVE_PREFIX) ? 1 : 0;
         step_fused = (f & EKF_FORM_STEP_FUSED) ? ((f & EKF_FORM_STEP_SPLIT_PASS) ? 1 : 2) : 0;
@@ -281,7 +255,6 @@ struct Pool {
         column_panel = (f & EKF_FORM_COLUMN_PANEL) ? ((f & EKF_FORM_COLUMN_PANEL_ONE_SLOT) ? 2 : 1) : 0;
         tuning.row_packing = (f & EKF_FORM_ROW_PACKING) ? 1 : 0;
         tuning.strip_flush = (f & EKF_FORM_STRIP_FLUSH_ALWAYS) ? 2 : (f & EKF_FORM_STRIP_FLUSH) ? 1 : 0;
-        alt_synced = false;
         return EKF_OK;
     }
     void set_tuning(int rows_per_block, int nontemporal, int group_rows) {
@@ -359,7 +332,6 @@ struct Pool {
     // fold every pending correction into Sigma_base (no-op in eager mode)
     ekf_status flush(const ekf::PanelIO& panel = ekf::PanelIO{nullptr, nullptr, nullptr, 0}) {
         if (pend_count > 0) {
-            alt_synced = false;
             form_counts[ekf::launch_flush(pv, pending(), tuning, stream, panel)]++;
             HIPC(hipGetLastError());
             pend_count = 0;
@@ -393,16 +365,6 @@ struct Pool {
         EKFC(flush());
         ekf::PoolView view = pv;
         if (active_N > 0 && active_N < pv.N) view.N = active_N;
-        if (fused_ok()) {  // single filter: gain + state + covariance in one launch, out of place
-            EKFC(ensure_alt());
-            EKFC(prof_begin(0));
-            ekf::launch_correct_fused(view, src, sigma_alt, state_fz, stream);
-            EKFC(prof_end());
-            std::swap(pv.sigma, sigma_alt);
-            std::swap(pv.state, state_fz);
-            return EKF_OK;
-        }
-        alt_synced = false;
         ekf::launch_gain(view, src, stream);
         EKFC(prof_begin(0));
         if (active_set && active_N == 0) ekf::launch_rank2_active(pv, tuning, touched_bound, stream);
@@ -536,7 +498,6 @@ struct Pool {
         ekf::launch_init(pv, stream);
         HIPC(hipGetLastError());
         init_flag = 0;
-        alt_synced = false;
         dev_known_count = 0;  // k_init resets the association record
         return EKF_OK;
     }
@@ -548,7 +509,7 @@ struct Pool {
         void* ptrs[] = {pv.sigma, pv.state, pv.Kg, pv.Gh, pv.snap, pv.rec, pv.assoc, pv.touch_flag, pv.touch_list,
                         pv.touch_count, scores, meas_dev, assoc_block,
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
-                        Uf, Vf, state_alt, sigma_alt, state_fz, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
+                        Uf, Vf, state_alt, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
                         phase_trace, terms2, scores2, blk_cache, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred,
                         colp, lmslot, plan_list};
         for (void* p : ptrs)
@@ -643,7 +604,6 @@ struct Pool {
         if (!in || b < 0 || b >= pv.B) return fail(EKF_ERR_INVALID, "set_cov: bad argument");
         EKFC(use());
         EKFC(flush());
-        alt_synced = false;
         touched_hwm = pv.n;  // caller-supplied covariance: no structure may be assumed any more
         touched_bound = pv.n;
         std::fill(host_touched.begin(), host_touched.end(), 1);

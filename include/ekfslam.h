@@ -123,10 +123,10 @@ typedef enum {
      * a pool (while 3 + 2*(known_count + readings) <= 104) or a whole run of a known-association log is ONE launch with
      * Sigma resident in LDS (ekf_small.hip).  Off: the multi-kernel chain. */
     EKF_FORM_SMALL_MAP = 1u << 0,
-    /* single filter, per-landmark path: gain + state + covariance of a correction (and decision + correction of an
-     * association) in ONE launch that writes Sigma - K(H Sigma) out of place into a second N x N buffer (ekf_fused.hip).
-     * Off: gain launch + in-place rank-2 stream, as pools do. */
-    EKF_FORM_FUSED_CORRECTION = 1u << 1,
+    /* (1u << 1: retired in round 4.  It was EKF_FORM_FUSED_CORRECTION -- gain + state + covariance of a correction in one
+     * launch that wrote Sigma - K(H Sigma) out of place into a second N x N buffer; tools/forms_ab.py measured it 2.5-4.7x
+     * behind the call-fused forms on measurement() and 1.3-1.5x behind them on data_association() at every map size, so
+     * the kernels and the second buffer were deleted.  The bit is ignored.) */
     /* beyond the small-map path: measurement() as TWO launches per call whatever the number of visible landmarks --
      * the gains K_v and rows H_v Sigma of all the call's corrections from two thin panels of Sigma, then ONE
      * read-modify-write pass in which every element takes its V rank-2 corrections in order: 16 N^2 bytes per CALL

@@ -44,7 +44,7 @@ def test_two_ranks_through_torchrun_aggregate_like_one():
     # weak scaling: every rank does the single-rank job's work -> twice the corrections in the aggregate
     work_a = a["value"] * a["ms_per_step"] * a["steps"]
     work_b = b["value"] * b["ms_per_step"] * b["steps"]
-    assert abs(work_b / work_a - 2.0) < 1e-9
+    assert abs(work_b / work_a - 2.0) < 1e-6   # (the line carries 9 significant digits)
     assert b["metric"] == a["metric"] and b["unit"] == a["unit"] and b["steps"] == 3 and b["warmup"] == 1
     # the driver's contract keys, on both lines
     for d in (a, b):

@@ -144,11 +144,11 @@ def test_call_fused_pool_on_device_log_full_size(hip):
     assert res[0][3]["rank2_launches"] * 2 == res[1][3]["rank2_launches"]   # V = 2 corrections per call
 
 
-@pytest.mark.parametrize("n,vmax,fused", [(750, 6, True), (750, 6, False), (800, 12, True), (1000, 8, True)])
-def test_call_fused_data_association_bitwise_and_vs_checker(hip, oracle, n, vmax, fused):
+@pytest.mark.parametrize("n,vmax", [(750, 6), (800, 12), (1000, 8), (470, 7)])
+def test_call_fused_data_association_bitwise_and_vs_checker(hip, oracle, n, vmax):
     """data_association() beyond the LDS-resident path with Sigma streamed once per call (ekf_assocfused.hip: one launch
     per reading against the stored covariance minus the call's pending pairs, one k_rank2v pass per 8 readings) against
-    the round-1 forms (two launches per reading with the fused correction, or four) bit for bit, and against the checker:
+    the per-reading chain (k_maha, k_assoc_decide, k_gain, k_rank2: four launches per reading) bit for bit, and against the checker:
     new landmarks, matched landmarks, dropped readings (1 <= d < 10), calls longer than one pass, measurement() in between."""
     T = 14 if n < 1000 else 12
     cfg = synth.SimConfig(n=n, steps=T, filters=1, seed=77 + n, half_extent=12.0, min_spacing=0.3,
@@ -158,8 +158,7 @@ def test_call_fused_data_association_bitwise_and_vs_checker(hip, oracle, n, vmax
     res = []
     for cf in (True, False):
         f = _single(hip, n, cf)
-        f.set_fused_correction(fused)
-        f.set_active_prefix(False)    # full-width corrections: the once-per-call path serves active dimensions >= 1400
+        f.set_active_prefix(False)    # full-width corrections: beyond the one-workgroup form from the first reading on
         known = np.zeros(n, dtype=np.uint8)
         decs = []
         r = np.random.default_rng(9)
@@ -180,7 +179,7 @@ def test_call_fused_data_association_bitwise_and_vs_checker(hip, oracle, n, vmax
     assert all(np.array_equal(a, b) for a, b in zip(res[0][2], res[1][2]))
     assert np.array_equal(res[0][3], res[1][3]) and res[0][3].sum() >= 6
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-    if n <= 800 and vmax == 6 and fused:   # and the checker (decisions first)
+    if n <= 800 and vmax <= 7:   # and the checker (decisions first)
         o = oracle.OracleEKF(n, oracle.STRUCTURED)
         ko = np.zeros(n, dtype=np.uint8)
         r = np.random.default_rng(9)

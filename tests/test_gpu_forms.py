@@ -1,5 +1,8 @@
-"""-m gpu: the single-launch out-of-place correction (ekf_fused.hip; default for single filters beyond the small-map
-path) against the two-launch form (k_gain + in-place k_rank2) bit for bit, and against the CPU checker."""
+"""-m gpu: a single filter's default launch structures beyond the small-map path (measurement() as two launches per call,
+data_association() as one launch per call or per reading) against the per-landmark chain (k_gain + in-place k_rank2; k_maha,
+k_assoc_decide, k_gain, k_rank2 per reading) bit for bit, and against the CPU checker.  (Until round 4 this file covered a
+third form, an out-of-place correction launch with a second N x N buffer; tools/forms_ab.py measured it behind the
+call-fused forms at every map size and it was deleted.)"""
 import numpy as np
 import pytest
 
@@ -15,11 +18,11 @@ def _known_cfg(n, T, seed):
 
 
 @pytest.mark.parametrize("n", [60, 200])
-def test_fused_known_equals_two_launch_form_and_checker(hip, oracle, n):
+def test_default_known_equals_per_landmark_chain_and_checker(hip, oracle, n):
     cfg = _known_cfg(n, 40, 300 + n)
     log = synth.make_known_log(cfg)
     f, g = hip.EKF_SLAM(n), hip.EKF_SLAM(n)
-    g.set_fused_correction(False)
+    g.set_call_fused(False)
     o = oracle.OracleEKF(n, oracle.STRUCTURED)
     for t in range(cfg.steps):
         s, v = log.expand_step(t)
@@ -32,13 +35,13 @@ def test_fused_known_equals_two_launch_form_and_checker(hip, oracle, n):
     f.close(); g.close()
 
 
-def test_fused_unknown_equals_two_launch_form_and_checker(hip, oracle):
+def test_default_unknown_equals_per_reading_chain_and_checker(hip, oracle):
     n, T = 80, 60
     cfg = synth.SimConfig(n=n, steps=T, filters=1, seed=808, half_extent=3.0, min_spacing=0.45, v_cmd=0.3, w_cmd=0.1,
                           max_visible_dis=1.2, vmax=8)
     log = synth.make_unknown_log(cfg)
     f, g = hip.EKF_SLAM(n), hip.EKF_SLAM(n)
-    g.set_fused_correction(False)
+    g.set_call_fused(False)
     o = oracle.OracleEKF(n, oracle.DENSE)
     kf, kg, ko = (np.zeros(n, dtype=np.uint8) for _ in range(3))
     dropped = 0
@@ -48,15 +51,14 @@ def test_fused_unknown_equals_two_launch_form_and_checker(hip, oracle):
         a, b, c = f.data_association(m, kf), g.data_association(m, kg), o.data_association(m, ko)
         assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(kf, ko)
         dropped += int((a < 0).sum())
-    assert kf.sum() >= 10 and f.N > 104  # N = 163: beyond the small-map path, so every correction took the fused launch
+    assert kf.sum() >= 10 and f.N > 104  # N = 163: beyond the small-map path
     assert np.array_equal(f.state, g.state) and np.array_equal(f.cov, g.cov)
     assert_parity(f.state, f.cov, o.state, o.cov, FP64_TOL, "fused unknown")
     f.close(); g.close()
 
 
-def test_fused_survives_mode_switches_and_snapshots(hip, oracle):
-    """Everything that rewrites Sigma in place between fused corrections (set_cov, delayed flushes, the two-launch form,
-    clone) must leave the second buffer consistent."""
+def test_forms_survive_mode_switches_and_snapshots(hip, oracle):
+    """Switching forms and update modes on a live object, set_cov / set_state round trips and clone must not disturb it."""
     n = 70
     cfg = _known_cfg(n, 36, 5150)
     log = synth.make_known_log(cfg)
@@ -65,9 +67,9 @@ def test_fused_survives_mode_switches_and_snapshots(hip, oracle):
     for t in range(cfg.steps):
         s, v = log.expand_step(t)
         if t == 8:
-            f.set_fused_correction(False)
+            f.set_call_fused(False)
         if t == 12:
-            f.set_fused_correction(True)
+            f.set_call_fused(True)
         if t == 16:
             f.set_update_mode(4)
         if t == 22:
@@ -83,9 +85,8 @@ def test_fused_survives_mode_switches_and_snapshots(hip, oracle):
     f.close()
 
 
-def test_fused_dropped_measurement_keeps_everything(hip):
-    """A measurement between the two gates (ekf_slam.cpp:330) corrects nothing: the out-of-place path must carry
-    state and covariance over unchanged."""
+def test_dropped_measurement_keeps_everything(hip):
+    """A measurement between the two gates (ekf_slam.cpp:330) corrects nothing: state and covariance stay as they are."""
     n = 60
     f = hip.EKF_SLAM(n)
     k = np.zeros(n, dtype=np.uint8)

@@ -18,7 +18,7 @@ def _scenario(hip, oracle, seed):
     f.set_update_mode(mode, symmetric_gather=False)
     f.set_small_map_path(bool(rng.integers(0, 2)))
     f.set_active_prefix(bool(rng.integers(0, 2)))
-    f.set_fused_correction(bool(rng.integers(0, 2)))
+    rng.integers(0, 2)   # (draw of a form that left the library in round 4: the scenarios keep their inputs)
     rng2 = np.random.default_rng(seed + 7919)   # (a second stream: the scenarios of round 1 keep their inputs)
     f.set_call_fused(bool(rng2.integers(0, 2)))                                   # two launches per measurement() call
     rng2.integers(0, 2), rng2.choice([0, 3, 17, 64])   # (draws of a path that left the library: the scenarios keep their inputs)
@@ -29,7 +29,7 @@ def _scenario(hip, oracle, seed):
     assoc_p = float(rng.choice([0.0, 0.0, 0.5, 1.0]))   # share of steps that go through data_association()
     for t in range(int(rng.integers(6, 22))):
         if rng.random() < 0.1:                          # live switches must not disturb the filter
-            f.set_fused_correction(bool(rng.integers(0, 2)))
+            rng.integers(0, 2)   # (see above)
         if rng2.random() < 0.1:
             f.set_call_fused(bool(rng2.integers(0, 2)))
         if rng2.random() < 0.1:

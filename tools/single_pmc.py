@@ -9,7 +9,7 @@ fused = (sys.argv[1] != "0") if len(sys.argv) > 1 else True
 cfg = synth.config3(steps=60)
 log = synth.make_known_log(cfg)
 f = capi.EKF_SLAM(1000)
-f.set_fused_correction(fused)
+f.set_call_fused(fused)
 t0 = time.perf_counter(); corr = 0
 for t in range(cfg.steps):
     s, v = log.expand_step(t)

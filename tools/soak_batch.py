@@ -44,7 +44,7 @@ for seed in range(N_SCEN):
     ok = True
     for b in range(B):
         f = hip.EKF_SLAM(n)
-        f.set_fused_correction(bool(rng.integers(0, 2)))
+        f.set_call_fused(bool(rng.integers(0, 2)))
         k = np.zeros(n, dtype=np.uint8)
         if surveyed:
             f.prediction((0.0, 0.0)); f.measurement(init[b], np.zeros(n, dtype=np.uint8))
