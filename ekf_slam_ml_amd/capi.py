@@ -40,7 +40,7 @@ SYMBOLS = [
     "ekf_circle_fit_scans", "ekf_normalize_angles",
     "ekf_default_lidar_params", "ekf_batch_simulate_unknown_log", "ekf_batch_download_unknown_log", "ekf_simulate_scans",
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
-    "ekf_dense_launch_info", "ekf_batch_rank2_variant",
+    "ekf_dense_launch_info", "ekf_dense_tile_map", "ekf_batch_rank2_variant",
     "ekf_set_profiling", "ekf_get_profile", "ekf_batch_set_known_counts",
     "ekf_set_forms", "ekf_get_forms", "ekf_batch_set_forms", "ekf_batch_get_forms", "ekf_batch_form_counts",
     "ekf_phase_trace",
@@ -181,6 +181,7 @@ def load():
         "ekf_dense_propagate": [h, C.c_int, _dp],
         "ekf_dense_get_sigma": [h, _fp],
         "ekf_dense_launch_info": [h, _ip, _ip, _ip, _ip],
+        "ekf_dense_tile_map": [h, _bp],
         "ekf_batch_rank2_variant": [h, _ip, _ip, _ip, _ip],
         "ekf_batch_set_known_counts": [h, _ip],
         "ekf_set_profiling": [h, C.c_int],
@@ -670,10 +671,18 @@ class DensePropagator:
         return out
 
     def launch_info(self):
-        """{ld, tiles, n_big, n_tail}: how one product is cut into full tiles and quarter-tile tail (test hook)"""
+        """{ld, tiles, n_big, n_tail}: how one product is cut into 256 x 128 tiles and a quarter-tile tail (test hook)"""
         v = [C.c_int() for _ in range(4)]
         _check(self._lib.ekf_dense_launch_info(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("ld", "tiles", "n_big", "n_tail"), (x.value for x in v)))
+
+    def tile_map(self):
+        """bool [tiles][tiles] over the 128 x 128 blocks of the result: True = computed by the tail kernel"""
+        t = self.launch_info()["tiles"]
+        m = np.zeros(t * t, dtype=np.uint8)
+        _check(self._lib.ekf_dense_tile_map(self._h, m.ctypes.data_as(_bp)))
+        assert set(np.unique(m)) <= {0, 1}, "a block of the result is computed by no kernel"
+        return m.reshape(t, t).astype(bool)
 
 
 MAX_CLUSTERS = 128

@@ -121,6 +121,12 @@ ekf_status ekf_dense_launch_info(ekf_dense_handle d, int* ld, int* tiles, int* n
     return EKF_OK;
 }
 
+ekf_status ekf_dense_tile_map(ekf_dense_handle d, unsigned char* map) {
+    if (!d || !map) return fail(EKF_ERR_INVALID, "null argument");
+    ekf::dense_gemm_tile_map(d->ld, d->stream2 != nullptr, map);
+    return EKF_OK;
+}
+
 ekf_status ekf_dense_get_sigma(ekf_dense_handle d, float* out) {
     if (!d || !out) return fail(EKF_ERR_INVALID, "null argument");
     HIPC(hipSetDevice(d->device));

@@ -11,10 +11,11 @@ constexpr int kDenseTile = 128;  // ld must be a multiple of this
 // around the call (both must be after the producers of A and B; consumers of C must wait for both).
 void launch_dense_gemm(const float* A, const float* B, float* C, const float* Qadd, int ld, bool b_transposed,
                        hipStream_t s, hipStream_t s_tail);
-// how launch_dense_gemm cuts the ld/128 x ld/128 tile list: n_big full 128 x 128 tiles (k_gemm_f32) and n_rem tiles
-// done as 4 * n_rem quarter tiles (k_gemm_f32_tail, only with a tail stream)
+// how launch_dense_gemm cuts a product: *tiles = ld / 128; n_big tiles of 256 x 128 on the main kernel (k_gemm_f32_big,
+// whole rounds of resident workgroups); n_rem tiles of 128 x 128 -- the rest of the big-tile list and the bottom strip of
+// an ld that is an odd multiple of 128 -- done as 4 * n_rem quarter tiles (k_gemm_f32_tail)
 void dense_gemm_split(int ld, bool has_tail_stream, int* tiles, int* n_big, int* n_rem);
-size_t dense_gemm_lds_bytes(bool b_transposed);
-void dense_gemm_set_buffers(int nbuf);  // 1 (default) or 2 LDS buffers per workgroup
-hipError_t dense_gemm_prepare();  // raises the dynamic-LDS limit of both instantiations (66 KB > 64 KB default)
+// map [tiles][tiles] over the 128 x 128 blocks of C: 0 = computed by the main kernel, 1 = by the tail kernel (255 never)
+void dense_gemm_tile_map(int ld, bool has_tail_stream, unsigned char* map);
+hipError_t dense_gemm_prepare();  // raises the dynamic-LDS limit of the main kernel (49.4 KB per workgroup)
 }  // namespace ekf

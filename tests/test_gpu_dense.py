@@ -80,43 +80,23 @@ def test_dense_reproduces_the_structured_prediction(hip, oracle):
     d.close()
 
 
-# ---- the path the published N = 10003 figure comes from: > 768 tiles, tile count not divisible by 8 -> the main
-# ---- kernel runs whole rounds of 128 x 128 tiles (grouped order, several groups, ragged last group) and
-# ---- k_gemm_f32_tail finishes the rest as 64 x 64 quarters on the second stream (ekf_dense.hip launch_dense_gemm)
-
-def _tile_of(bid, tiles):
-    """host twin of ekf_dense.hip tile_of() for tile counts that do not divide 8 (no XCD remap)"""
-    assert (tiles * tiles) % 8 != 0
-    group_m = 8
-    per_group = group_m * tiles
-    g = bid // per_group
-    first_m = g * group_m
-    gm = min(group_m, tiles - first_m)
-    in_g = bid % per_group
-    return first_m + in_g % gm, in_g // gm
-
-
-def _tail_mask(info):
-    """boolean [tiles][tiles]: tiles computed by k_gemm_f32_tail"""
-    t = info["tiles"]
-    m = np.zeros((t, t), dtype=bool)
-    for bid in range(info["n_big"], info["n_big"] + info["n_tail"]):
-        tm, tn = _tile_of(bid, t)
-        m[tm, tn] = True
-    return m
-
+# ---- the path the published N = 10003 figure comes from: the main kernel runs whole rounds of 256 x 128 tiles (grouped
+# ---- order, XCD-remapped), k_gemm_f32_tail finishes the rest of the list and the bottom strip of an ld that is an odd
+# ---- multiple of 128 as 64 x 64 quarters on the second stream (ekf_dense.hip launch_dense_gemm).  Which kernel computes
+# ---- which 128 x 128 block comes from the library itself (ekf_dense_tile_map: the host side of the kernels' own maps).
 
 def test_dense_tail_path_exact_and_fp64(hip):
-    """ld = 3712 -> 29 x 29 = 841 tiles = 768 (one full round, 4 tile groups incl. a ragged one) + 73 tail tiles.
+    """N = 4700: ld = 4736 = 37 x 128 -> 18 x 37 = 666 tiles of 256 x 128 = 512 (one full round, three
+    tile groups incl. a ragged one) + 154 left over = 308 tail tiles of 128 x 128, + the bottom strip of 37: 345 tail tiles.
     (1) exact-integer operands, all three matrices asymmetric, + Q: every element must be bit-exact, which pins the
     tile -> (row, col) maps of BOTH kernels and the two-stream join; (2) random dense F against fp64 per block."""
-    N = 3600
+    N = 4700
     d = hip.DensePropagator(N)
     info = d.launch_info()
-    assert info["ld"] == 3712 and info["tiles"] == 29
-    assert info["n_big"] == 768 and info["n_tail"] == 73, info   # the test cannot silently take the one-kernel path
-    mask = _tail_mask(info)
-    assert mask.sum() == 73
+    assert info["ld"] == 4736 and info["tiles"] == 37
+    assert info["n_big"] == 512 and info["n_tail"] == 345, info   # the test cannot silently take the one-kernel path
+    mask = d.tile_map()
+    assert mask.sum() == 345 and mask[36].all() and not mask[0, :8].any()
 
     rng = np.random.default_rng(29)
     B = rng.integers(-1, 2, size=(N, N)).astype(np.float32)   # {-1, 0, 1}: every partial sum stays far below 2^24
@@ -156,13 +136,15 @@ def test_dense_tail_path_exact_and_fp64(hip):
 
 
 def test_dense_full_size_n5000_rows_in_tail_tiles(hip):
-    """BASELINE.json configs[3] at its full size N = 10003 (n = 5000, ld = 10112, 79 x 79 = 6241 tiles = 8 rounds
-    of 768 + 97 tail tiles): rows sampled INSIDE tail tiles (and a few outside) against fp64."""
+    """BASELINE.json configs[3] at its full size N = 10003 (n = 5000, ld = 10112 = 79 x 128: 39 x 79 = 3081 tiles of
+    256 x 128 = 6 rounds of 512 + 9 left over -> 18 tail tiles, + the bottom strip of 79: 97 tail tiles of 128 x 128): rows
+    sampled INSIDE tail tiles (and a few outside) against fp64."""
     N = 10003
     d = hip.DensePropagator(N)
     info = d.launch_info()
-    assert info["ld"] == 10112 and info["tiles"] == 79 and info["n_big"] == 6144 and info["n_tail"] == 97, info
-    mask = _tail_mask(info)
+    assert info["ld"] == 10112 and info["tiles"] == 79 and info["n_big"] == 3072 and info["n_tail"] == 97, info
+    mask = d.tile_map()
+    assert mask.sum() == 97 and mask[78].all()
     rng = np.random.default_rng(4)
     F = np.eye(N, dtype=np.float32) + rng.standard_normal((N, N), dtype=np.float32) * np.float32(0.05 / np.sqrt(N))
     A = rng.standard_normal((N, 64), dtype=np.float32)
