@@ -5,9 +5,9 @@ using namespace ekfrt;
 
 struct ekf_dense_s {
     int device = -1, N = 0, ld = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipStream_t stream = nullptr;
     float *F = nullptr, *S = nullptr, *T = nullptr, *Q = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr, j1 = nullptr, j2 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 
 extern "C" {
@@ -34,9 +34,6 @@ ekf_status ekf_dense_create(int N, int device, ekf_dense_handle* out) {
     auto body = [&]() -> ekf_status {
         HIPC(hipSetDevice(device));
         HIPC(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-        HIPC(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
-        HIPC(hipEventCreateWithFlags(&d->j1, hipEventDisableTiming));
-        HIPC(hipEventCreateWithFlags(&d->j2, hipEventDisableTiming));
         HIPC(ekf::dense_gemm_prepare());
         for (float** p : {&d->F, &d->S, &d->T, &d->Q}) {
             HIPC(hipMalloc((void**)p, bytes));
@@ -62,11 +59,9 @@ ekf_status ekf_dense_destroy(ekf_dense_handle d) {
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     for (float* p : {d->F, d->S, d->T, d->Q})
         if (p) (void)hipFree(p);
-    if (d->stream2) (void)hipStreamSynchronize(d->stream2);
-    for (hipEvent_t e : {d->e0, d->e1, d->j1, d->j2})
+    for (hipEvent_t e : {d->e0, d->e1})
         if (e) (void)hipEventDestroy(e);
     if (d->stream) (void)hipStreamDestroy(d->stream);
-    if (d->stream2) (void)hipStreamDestroy(d->stream2);
     delete d;
     return EKF_OK;
 }
@@ -87,22 +82,10 @@ ekf_status ekf_dense_propagate(ekf_dense_handle d, int iterations, double* elaps
     if (!d || iterations < 0) return fail(EKF_ERR_INVALID, "ekf_dense_propagate: bad argument");
     HIPC(hipSetDevice(d->device));
     HIPC(hipEventRecord(d->e0, d->stream));
-    // both streams meet before and after every product: the tail kernel on stream2 reads what the previous
-    // product wrote on either stream, and the next product reads what both kernels of this one wrote
-    auto join = [&]() -> ekf_status {
-        HIPC(hipEventRecord(d->j1, d->stream));
-        HIPC(hipStreamWaitEvent(d->stream2, d->j1, 0));
-        HIPC(hipEventRecord(d->j2, d->stream2));
-        HIPC(hipStreamWaitEvent(d->stream, d->j2, 0));
-        return EKF_OK;
-    };
     for (int it = 0; it < iterations; it++) {
-        EKFC(join());
-        ekf::launch_dense_gemm(d->F, d->S, d->T, nullptr, d->ld, false, d->stream, d->stream2);  // T = At*sigma (:102)
-        EKFC(join());
-        ekf::launch_dense_gemm(d->T, d->F, d->S, d->Q, d->ld, true, d->stream, d->stream2);  // sigma = T*At.t() + Q
+        ekf::launch_dense_gemm(d->F, d->S, d->T, nullptr, d->ld, false, d->stream, d->N);  // T = At*sigma (:102)
+        ekf::launch_dense_gemm(d->T, d->F, d->S, d->Q, d->ld, true, d->stream, d->N);      // sigma = T*At.t() + Q
     }
-    EKFC(join());
     HIPC(hipEventRecord(d->e1, d->stream));
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(d->stream));
@@ -117,13 +100,13 @@ ekf_status ekf_dense_propagate(ekf_dense_handle d, int iterations, double* elaps
 ekf_status ekf_dense_launch_info(ekf_dense_handle d, int* ld, int* tiles, int* n_big, int* n_tail) {
     if (!d) return fail(EKF_ERR_INVALID, "null handle");
     if (ld) *ld = d->ld;
-    ekf::dense_gemm_split(d->ld, d->stream2 != nullptr, tiles, n_big, n_tail);
+    ekf::dense_gemm_split(d->ld, tiles, n_big, n_tail);
     return EKF_OK;
 }
 
 ekf_status ekf_dense_tile_map(ekf_dense_handle d, unsigned char* map) {
     if (!d || !map) return fail(EKF_ERR_INVALID, "null argument");
-    ekf::dense_gemm_tile_map(d->ld, d->stream2 != nullptr, map);
+    ekf::dense_gemm_tile_map(d->ld, map);
     return EKF_OK;
 }
 

@@ -48,6 +48,8 @@ __host__ __device__ inline void big_tile_of(int id, int tiles_m, int tiles_n, in
 // tail kernel, which cuts each of them into four 64 x 64 quarters.
 struct DenseSplit {
     int ld, tiles_n, tiles_m, n_big, rem_big, bottom, n_small;
+    int n_rows;   // rows of C that are not padding (N): a quarter tile that lies wholly below them is not computed -- its
+                  // rows of C are products of A's zero padding and stay the zeros they were allocated as
 };
 // origin of small tile q (units: elements)
 __host__ __device__ inline void small_tile_origin(const DenseSplit& sp, int q, int& row0, int& col0) {
@@ -215,10 +217,13 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
 
 // N = 10003 (ld = 10112): 39 x 79 = 3081 tiles of 256 x 128 over 512 resident workgroup slots (2 per CU) = 6 whole rounds
 // (3072 tiles) on the main kernel; the other 9 big tiles (18 tiles of 128 x 128) and the bottom strip (79 tiles of
-// 128 x 128: ld is 39.5 x 256) are cut into 64 x 64 quarters on the tail kernel, launched on a second stream so that its
-// workgroups fill the slots the main kernel's last round leaves idle (speed only).
-// (Rounds 1-3 ran 128 x 128 tiles, three workgroups per CU: 0.76-0.80 of the f32 matrix peak in the steady state of the
-// main kernel itself -- 4 LDS fragment reads per 4 MFMAs, 32 staging stores and two barriers per 64 MFMAs of a wave.)
+// 128 x 128: ld is 39.5 x 256) are cut into 64 x 64 quarters on the tail kernel, which follows on the same stream
+// (0.55-0.62 ms; quarters that hold padding rows only are skipped).
+// Measured, tools/dense_bench.py at N = 10003: rounds 1-3 ran 128 x 128 tiles, three workgroups per CU, with the tail on a
+// second stream: 32.6 ms per propagation (0.76-0.80 of the f32 matrix peak in the steady state of the main kernel itself:
+// 4 LDS fragment reads per 4 MFMAs, 32 staging stores and two barriers per 64 MFMAs of a wave).  256 x 128 tiles: 30.7 ms;
+// the tail on a lowest-priority second stream: 30.3 ms (its quarter tiles slow the main kernel of the NN product by more
+// than their own 0.6 ms when they share the chip with it); the tail behind the main kernel: 30.15 ms = 132.8 TFLOP/s.
 template <bool BT>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32_big(const float* __restrict__ A, const float* __restrict__ B,
                                                          float* __restrict__ C, const float* __restrict__ Qadd,
@@ -241,7 +246,9 @@ __global__ __launch_bounds__(256, 4) void k_gemm_f32_tail(const float* __restric
     const int s = blockIdx.x;
     int row0, col0;
     small_tile_origin(sp, s >> 2, row0, col0);
-    gemm_tile<BT, 1, 1, 1>(A, B, C, Qadd, sp.ld, row0 + ((s >> 1) & 1) * 64, col0 + (s & 1) * 64, smem);
+    row0 += ((s >> 1) & 1) * 64;
+    if (row0 >= sp.n_rows) return;   // (uniform) padding rows only: at N = 10003 half of the bottom strip's quarters
+    gemm_tile<BT, 1, 1, 1>(A, B, C, Qadd, sp.ld, row0, col0 + (s & 1) * 64, smem);
 }
 
 static size_t lds_bytes(int tm, int tn, bool bt) {
@@ -258,31 +265,32 @@ hipError_t dense_gemm_prepare() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 128, false));
 }
 
-static DenseSplit make_split(int ld, bool has_tail_stream) {
+static DenseSplit make_split(int ld, int n_rows = 0) {
     DenseSplit sp{};
     sp.ld = ld;
+    sp.n_rows = n_rows > 0 ? n_rows : ld;
     sp.tiles_n = ld / kDenseTile;
     sp.tiles_m = ld / (2 * kDenseTile);
     sp.bottom = (ld % (2 * kDenseTile)) ? 1 : 0;
     const int total_big = sp.tiles_m * sp.tiles_n;
     const int slots = 256 * 2;   // resident workgroups: __launch_bounds__ of k_gemm_f32_big
     int n_big = total_big / slots * slots;
-    if (!has_tail_stream || n_big == 0) n_big = total_big;   // (nothing to overlap the remainder with)
+    if (n_big == 0) n_big = total_big;   // (less than one round: all of it on the main kernel)
     sp.n_big = n_big;
     sp.rem_big = total_big - n_big;
     sp.n_small = 2 * sp.rem_big + sp.bottom * sp.tiles_n;
     return sp;
 }
 
-void dense_gemm_split(int ld, bool has_tail_stream, int* tiles_out, int* n_big_out, int* n_rem_out) {
-    const DenseSplit sp = make_split(ld, has_tail_stream);
+void dense_gemm_split(int ld, int* tiles_out, int* n_big_out, int* n_rem_out) {
+    const DenseSplit sp = make_split(ld);
     if (tiles_out) *tiles_out = sp.tiles_n;
     if (n_big_out) *n_big_out = sp.n_big;
     if (n_rem_out) *n_rem_out = sp.n_small;
 }
 
-void dense_gemm_tile_map(int ld, bool has_tail_stream, unsigned char* map) {
-    const DenseSplit sp = make_split(ld, has_tail_stream);
+void dense_gemm_tile_map(int ld, unsigned char* map) {
+    const DenseSplit sp = make_split(ld);
     const int t = sp.tiles_n;
     for (int i = 0; i < t * t; i++) map[i] = 255;
     for (int id = 0; id < sp.n_big; id++) {   // (the XCD remap permutes ids inside [0, n_big): the set of tiles is the same)
@@ -299,18 +307,17 @@ void dense_gemm_tile_map(int ld, bool has_tail_stream, unsigned char* map) {
 }
 
 void launch_dense_gemm(const float* A, const float* B, float* C, const float* Qadd, int ld, bool b_transposed,
-                       hipStream_t s, hipStream_t s_tail) {
-    const DenseSplit sp = make_split(ld, s_tail != nullptr);
+                       hipStream_t s, int n_rows) {
+    const DenseSplit sp = make_split(ld, n_rows);
     if (sp.n_big > 0) {
         const size_t lds = lds_bytes(256, 128, b_transposed);
         if (b_transposed) hipLaunchKernelGGL((k_gemm_f32_big<true>), dim3(sp.n_big), dim3(256), lds, s, A, B, C, Qadd, sp);
         else hipLaunchKernelGGL((k_gemm_f32_big<false>), dim3(sp.n_big), dim3(256), lds, s, A, B, C, Qadd, sp);
     }
-    if (sp.n_small > 0) {
+    if (sp.n_small > 0) {   // behind the main kernel on the same stream (see k_gemm_f32_big)
         const size_t lds = lds_bytes(64, 64, b_transposed);
-        hipStream_t st = s_tail ? s_tail : s;
-        if (b_transposed) hipLaunchKernelGGL((k_gemm_f32_tail<true>), dim3(4 * sp.n_small), dim3(256), lds, st, A, B, C, Qadd, sp);
-        else hipLaunchKernelGGL((k_gemm_f32_tail<false>), dim3(4 * sp.n_small), dim3(256), lds, st, A, B, C, Qadd, sp);
+        if (b_transposed) hipLaunchKernelGGL((k_gemm_f32_tail<true>), dim3(4 * sp.n_small), dim3(256), lds, s, A, B, C, Qadd, sp);
+        else hipLaunchKernelGGL((k_gemm_f32_tail<false>), dim3(4 * sp.n_small), dim3(256), lds, s, A, B, C, Qadd, sp);
     }
 }
 

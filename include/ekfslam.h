@@ -382,8 +382,8 @@ ekf_status ekf_dense_propagate(ekf_dense_handle h, int iterations, double* elaps
 ekf_status ekf_dense_get_sigma(ekf_dense_handle h, float* out);
 /* Test / report hook: how one product of this handle is launched -- ld (N rounded up to 128), tiles = ld / 128 per
  * side, n_big = 256 x 128 tiles run by the main kernel (whole rounds of resident workgroups), n_tail = 128 x 128 tiles
- * cut into 64 x 64 quarters for the tail kernel on the second stream (what is left of the big-tile list, and the
- * bottom strip of an ld that is an odd multiple of 128).  Any pointer may be NULL. */
+ * cut into 64 x 64 quarters for the tail kernel behind it (what is left of the big-tile list, and the bottom strip of an
+ * ld that is an odd multiple of 128).  Any pointer may be NULL. */
 ekf_status ekf_dense_launch_info(ekf_dense_handle h, int* ld, int* tiles, int* n_big, int* n_tail);
 /* ... and which kernel computes which 128 x 128 block of the result: map[tiles * tiles], row-major over blocks,
  * 0 = main kernel, 1 = tail kernel (the tests sample rows inside tail tiles with it). */

@@ -82,14 +82,14 @@ def test_dense_reproduces_the_structured_prediction(hip, oracle):
 
 # ---- the path the published N = 10003 figure comes from: the main kernel runs whole rounds of 256 x 128 tiles (grouped
 # ---- order, XCD-remapped), k_gemm_f32_tail finishes the rest of the list and the bottom strip of an ld that is an odd
-# ---- multiple of 128 as 64 x 64 quarters on the second stream (ekf_dense.hip launch_dense_gemm).  Which kernel computes
+# ---- multiple of 128 as 64 x 64 quarters behind it (ekf_dense.hip launch_dense_gemm).  Which kernel computes
 # ---- which 128 x 128 block comes from the library itself (ekf_dense_tile_map: the host side of the kernels' own maps).
 
 def test_dense_tail_path_exact_and_fp64(hip):
     """N = 4700: ld = 4736 = 37 x 128 -> 18 x 37 = 666 tiles of 256 x 128 = 512 (one full round, three
     tile groups incl. a ragged one) + 154 left over = 308 tail tiles of 128 x 128, + the bottom strip of 37: 345 tail tiles.
     (1) exact-integer operands, all three matrices asymmetric, + Q: every element must be bit-exact, which pins the
-    tile -> (row, col) maps of BOTH kernels and the two-stream join; (2) random dense F against fp64 per block."""
+    tile -> (row, col) maps of BOTH kernels; (2) random dense F against fp64 per block."""
     N = 4700
     d = hip.DensePropagator(N)
     info = d.launch_info()
