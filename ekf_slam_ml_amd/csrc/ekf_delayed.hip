@@ -35,6 +35,27 @@ __device__ __forceinline__ void xcd_decode(int id, int parts, int B, int& b, int
     }
 }
 
+// Column panel (see Pending::uvc): the lane that owns the indices r, r + 1 files the entries of the pairs it appends
+// (vectors [j0, j0 + NV), values k[q] / g[q] = U / V at (r, r + 1)) under the panel rows of those indices, if they have one
+template <int NV>
+__device__ __forceinline__ void uvc_append(const Pending& pend, int b, int n, int N, int r, int j0, const double2_t (&k)[NV],
+                                           const double2_t (&g)[NV]) {
+    if (!pend.uvc) return;
+    const short* lms = pend.lmslot + (size_t)b * n;
+    double2_t* uc = pend.uvc + (size_t)b * pend.colp_rows * pend.cap;
+    int pr0 = -1, pr1 = -1;
+    if (r < 3) pr0 = r; else if (r < N) { const int sl = lms[(r - 3) >> 1]; if (sl >= 0) pr0 = 3 + 2 * sl + ((r - 3) & 1); }
+    if (r + 1 < 3) pr1 = r + 1; else if (r + 1 < N) { const int sl = lms[(r - 2) >> 1]; if (sl >= 0) pr1 = 3 + 2 * sl + ((r - 2) & 1); }
+    if (pr0 >= 0) {
+#pragma unroll
+        for (int q = 0; q < NV; q++) uc[(size_t)pr0 * pend.cap + j0 + q] = double2_t{k[q].x, g[q].x};
+    }
+    if (pr1 >= 0) {
+#pragma unroll
+        for (int q = 0; q < NV; q++) uc[(size_t)pr1 * pend.cap + j0 + q] = double2_t{k[q].y, g[q].y};
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // One landmark correction in delayed mode: ekf_slam.cpp:137-187 without the covariance stream.
 // grid (ceil(ld/512), B).  Reads: state (in), Sigma_base, U/V rows [0, count); writes: U/V rows
@@ -92,6 +113,8 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
             *reinterpret_cast<double2_t*>(Ub + (size_t)(rc + 1) * ld + r) = zero2;
             *reinterpret_cast<double2_t*>(Vb + (size_t)rc * ld + r) = zero2;
             *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + 1) * ld + r) = zero2;
+            const double2_t z2[2] = {zero2, zero2};
+            if (!SYM) uvc_append<2>(pend, b, pv.n, N, r, rc, z2, z2);
         }
         if (part == 0 && tid == 0) pv.rec[b].active = 0;
         return;
@@ -102,11 +125,19 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
     // matrix's own columns 1, 2 are stale below the pose block while it is on
     const double* __restrict__ cp = (!SYM && pend.colp) ? pend.colp + (size_t)b * pend.colp_rows * ld : nullptr;
     const int slot = cp ? pend.lmslot[(size_t)b * pv.n + lm] : -1;
+    const double2_t* __restrict__ uc = (cp && pend.uvc) ? pend.uvc + (size_t)b * pend.colp_rows * pend.cap : nullptr;
     for (int idx = tid; idx < 5 * rc; idx += 256) {
         const int k = idx / rc, j = idx - k * rc;
         const int c = idx5(k, lm);
-        sh_U5[k * kMaxPending + j] = Ub[(size_t)j * ld + c];
-        sh_V5[k * kMaxPending + j] = Vb[(size_t)j * ld + c];
+        const int pr = k < 3 ? k : (slot >= 0 ? 3 + 2 * slot + (k - 3) : -1);
+        if (uc && pr >= 0) {   // the transposed copy: contiguous in j
+            const double2_t uv = uc[(size_t)pr * pend.cap + j];
+            sh_U5[k * kMaxPending + j] = uv.x;
+            sh_V5[k * kMaxPending + j] = uv.y;
+        } else {
+            sh_U5[k * kMaxPending + j] = Ub[(size_t)j * ld + c];
+            sh_V5[k * kMaxPending + j] = Vb[(size_t)j * ld + c];
+        }
     }
     __syncthreads();
     if (tid < 25) {
@@ -184,10 +215,10 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
         // folded in), unrolled by three so that a stage never changes registers: round 3's loop rotated the stages with
         // copies (ua = ua1 ...), and a copy of a register that a load is still writing waits for that load -- hipcc put
         // `s_waitcnt vmcnt(0)` at the top of every trip, i.e. ONE stage (64 B per lane) in flight: 4.0-4.8 TB/s of a
-        // kernel that streams count x 32 B per lane and is bandwidth-bound.  Trips past the end re-read pair 0.
+        // kernel that streams count x 32 B per lane and is bandwidth-bound.  Trips past the end re-read the last pair (a cache hit).
         struct Stage { double2_t ua, ub, va, vb; };
         auto ld4 = [&](int j, Stage& q) {
-            const int jj = j < rc ? j : 0;
+            const int jj = j < rc ? j : rc - 2;   // (past the end: the pair just read -- a cache hit, not a second fetch of pair 0)
             if (!SYM) {
                 q.ua = *reinterpret_cast<const double2_t*>(Ub + (size_t)jj * ld + r);
                 q.ub = *reinterpret_cast<const double2_t*>(Ub + (size_t)(jj + 1) * ld + r);
@@ -246,6 +277,10 @@ __global__ __launch_bounds__(256) void k_gain_delayed(PoolView pv, CmdSrc src, P
     *reinterpret_cast<double2_t*>(Vb + (size_t)rc * ld + r) = gv0;
     *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + 1) * ld + r) = gv1;
     *reinterpret_cast<double2_t*>(so + r) = snew;
+    if (!SYM) {
+        const double2_t kq[2] = {kv0, kv1}, gq[2] = {gv0, gv1};
+        uvc_append<2>(pend, b, pv.n, N, r, rc, kq, gq);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -293,6 +328,8 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
                 *reinterpret_cast<double2_t*>(Ub + (size_t)(rc + q) * ld + r) = zero2;
                 *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + q) * ld + r) = zero2;
             }
+            const double2_t z4[4] = {zero2, zero2, zero2, zero2};
+            if (!SYM) uvc_append<4>(pend, b, pv.n, N, r, rc, z4, z4);
         }
         if (part == 0 && tid == 0) pv.rec[b].active = 0;
         return;
@@ -368,11 +405,20 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
             }
         }
     }
+    const double2_t* __restrict__ uc = (cp && pend.uvc) ? pend.uvc + (size_t)b * pend.colp_rows * pend.cap : nullptr;
     for (int idx = tid; idx < 7 * rc; idx += 256) {
         const int k = idx / rc, j = idx - k * rc;
         const int c = cidx(k);
-        sh_U7[k * kMaxPending + j] = Ub[(size_t)j * ld + c];
-        sh_V7[k * kMaxPending + j] = Vb[(size_t)j * ld + c];
+        const int sl = k < 5 ? slot1 : slot2;
+        const int pr = k < 3 ? k : (sl >= 0 ? 3 + 2 * sl + ((k - 3) & 1) : -1);
+        if (uc && pr >= 0) {   // the transposed copy of the pending factors at the panel's indices: contiguous in j
+            const double2_t uv = uc[(size_t)pr * pend.cap + j];
+            sh_U7[k * kMaxPending + j] = uv.x;
+            sh_V7[k * kMaxPending + j] = uv.y;
+        } else {
+            sh_U7[k * kMaxPending + j] = Ub[(size_t)j * ld + c];
+            sh_V7[k * kMaxPending + j] = Vb[(size_t)j * ld + c];
+        }
     }
     __syncthreads();
     if (tid < 49) {
@@ -458,7 +504,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
         // really are in flight while pair j is folded in)
         struct Stage { double2_t ua, ub, va, vb; };
         auto ld4 = [&](int j, Stage& q) {
-            const int jj = j < rc ? j : 0;
+            const int jj = j < rc ? j : rc - 2;   // (past the end: the pair just read -- a cache hit, not a second fetch of pair 0)
             if (!SYM) {
                 q.ua = *reinterpret_cast<const double2_t*>(Ub + (size_t)jj * ld + r);
                 q.ub = *reinterpret_cast<const double2_t*>(Ub + (size_t)(jj + 1) * ld + r);
@@ -547,6 +593,10 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + 2) * ld + r) = g2a;
     *reinterpret_cast<double2_t*>(Vb + (size_t)(rc + 3) * ld + r) = g2b;
     *reinterpret_cast<double2_t*>(so + r) = snew;
+    if (!SYM) {
+        const double2_t kq[4] = {k1a, k1b, k2a, k2b}, gq[4] = {g1a, g1b, g2a, g2b};
+        uvc_append<4>(pend, b, pv.n, N, r, rc, kq, gq);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -586,10 +636,10 @@ __device__ __forceinline__ void flush_apply(double2_t (&a)[U_ROWS], const double
     // V of pair j+2 AND j+4 are in flight while pair j's FMAs run (PMC: with one pair of lookahead the waves
     // sat in s_waitcnt half of the time: an L2 hit under load outlasts one pair's 256 FMA cycles).  Three register
     // stages, unrolled by three: stages rotated by copies make hipcc wait for every load at the top of each trip (a copy
-    // of a register that a load is still writing waits for that load).  Trips past the end re-read pair 0.
+    // of a register that a load is still writing waits for that load).  Trips past the end re-read the last pair (a cache hit).
     struct Stage { double2_t v0, v1; };
     auto ldv = [&](int j, Stage& q) {
-        const int jj = j < count ? j : 0;
+        const int jj = j < count ? j : count - 2;
         q.v0 = Vb[(size_t)jj * ld2n];
         q.v1 = Vb[(size_t)(jj + 1) * ld2n];
     };

@@ -182,10 +182,14 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
         double* u = pend.U + ((size_t)b * pend.cap + j) * ld;
         double* v = pend.V + ((size_t)b * pend.cap + j) * ld;
         const double u0_ = u[0], v0_ = v[0];
-        u[1] = a10 * u0_ + u[1];
-        u[2] = a20 * u0_ + u[2];
-        v[1] = a10 * v0_ + v[1];
-        v[2] = a20 * v0_ + v[2];
+        const double u1 = a10 * u0_ + u[1], u2 = a20 * u0_ + u[2], v1 = a10 * v0_ + v[1], v2 = a20 * v0_ + v[2];
+        u[1] = u1; u[2] = u2;
+        v[1] = v1; v[2] = v2;
+        if (pend.uvc) {   // the transposed copy of the factors at the panel's indices (see Pending::uvc): indices 1, 2
+            double2_t* uc = pend.uvc + (size_t)b * pend.colp_rows * pend.cap;
+            uc[(size_t)1 * pend.cap + j] = double2_t{u1, v1};
+            uc[(size_t)2 * pend.cap + j] = double2_t{u2, v2};
+        }
     }
     if (threadIdx.x == 0) {
         st[0] = theta + u0;  // :99 -- theta is NOT wrapped after the prediction

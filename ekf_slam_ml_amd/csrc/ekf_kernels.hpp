@@ -61,6 +61,12 @@ struct Pending {
     double* colp;
     const short* lmslot;
     int colp_rows;   // rows of a filter's panel (3 + 2 x slots)
+    // ... and the pending factors' own entries at the panel's indices, transposed: uvc[b][panel row of index c][j] =
+    // (U_j(c), V_j(c)) for every pair j appended while this panel has been on.  A correction needs U_j, V_j at its 5 (7)
+    // core indices for all pending j: contiguous in j here, one 64-byte sector per 8-byte entry in the factor store
+    // (PMC, profiles/r04: 7 % of the gain kernel's fetched bytes).  Written by the lane that owns index c when it appends
+    // a pair, kept up (entries of the indices 1, 2) by prediction().
+    double2_t* uvc;
 };
 // flush <-> panel: `in` (nullable) = the panel that has been on since the last flush (its rows 1, 2 ARE the matrix's
 // columns 1, 2); `out` (nullable) = the panel to write for the landmarks of `lmslot`

@@ -265,7 +265,7 @@ struct Pool {
 
     ekf::Pending pending() const {
         ekf::Pending p{Uf, Vf, pend_cap, pend_count, pend_symmetric};
-        if (panel_active) { p.colp = colp; p.lmslot = lmslot; p.colp_rows = colp_rows(); }
+        if (panel_active) { p.colp = colp; p.lmslot = lmslot; p.colp_rows = colp_rows(); p.uvc = uvc; }
         return p;
     }
 
@@ -276,6 +276,7 @@ struct Pool {
     double* colp = nullptr;       // [B][3 + 2 slots][ld]
     short* lmslot = nullptr;      // [B][n]
     int* plan_list = nullptr;     // [B][slots]
+    ekf::double2_t* uvc = nullptr;   // [B][3 + 2 slots][cap]: (U_j(c), V_j(c)) of the pending factors at the panel's indices
     int colp_slots = 0;
     int column_panel = 1;         // 0 off, 1 on, 2 on with a ONE-slot plan (test hook: the gather fallback beside the panel)
     bool panel_valid = false, panel_active = false;
@@ -284,7 +285,8 @@ struct Pool {
         if (colp) HIPC(hipFree(colp));
         if (lmslot) HIPC(hipFree(lmslot));
         if (plan_list) HIPC(hipFree(plan_list));
-        colp = nullptr; lmslot = nullptr; plan_list = nullptr; colp_slots = 0;
+        if (uvc) HIPC(hipFree(uvc));
+        colp = nullptr; lmslot = nullptr; plan_list = nullptr; uvc = nullptr; colp_slots = 0;
         panel_valid = panel_active = false;
         return EKF_OK;
     }
@@ -302,6 +304,7 @@ struct Pool {
         HIPC(hipMalloc((void**)&colp, np * sizeof(double)));
         HIPC(hipMalloc((void**)&lmslot, nl * sizeof(short)));
         HIPC(hipMalloc((void**)&plan_list, nq * sizeof(int)));
+        HIPC(hipMalloc((void**)&uvc, (size_t)pv.B * colp_rows() * pend_cap * sizeof(ekf::double2_t)));
         HIPC(hipMemsetAsync(colp, 0, np * sizeof(double), stream));       // (pad entries of the rows stay 0)
         HIPC(hipMemsetAsync(lmslot, 0xFF, nl * sizeof(short), stream));   // -1: no landmark has a slot
         HIPC(hipMemsetAsync(plan_list, 0xFF, nq * sizeof(int), stream));
@@ -511,7 +514,7 @@ struct Pool {
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
                         phase_trace, terms2, scores2, blk_cache, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred,
-                        colp, lmslot, plan_list};
+                        colp, lmslot, plan_list, uvc};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();
