@@ -80,7 +80,7 @@ _FULL_PRECISION = {"value", "ms_per_step", "achieved", "frac", "avg_launch_ms", 
 # computed (and used by the checks inside bench.py) but not printed: derivable from what is
 _DROP = {"scores_per_s", "measurements", "corrections", "score_launches", "steps_per_flush", "covariance_GBps", "parity_filters",
          "known_landmarks_min", "corrections_per_launch", "kernel_launches", "fp64_check_rows", "touched_landmarks_max",
-         "hbm_bytes_per_gpu", "state_dim", "landmarks", "peak_nested", "achieved_GBps_on_declared_bytes", "launches_nested",
+         "hbm_bytes_per_gpu", "state_dim", "peak_nested", "achieved_GBps_on_declared_bytes", "launches_nested",
          "active_dimension_max", "measurement_slots", "steps_timed", "corrections_per_step"}
 
 
@@ -588,7 +588,8 @@ def main():
             delayed["max_abs_state_diff_vs_eager"] = float(np.abs(dstate - rstate).max())
             delayed["max_rel_cov_diff_vs_eager"] = float(np.abs(dcov - rcov).max() / np.abs(rcov).max())
             fcn = bt.form_counts()
-            delayed["flush_form"] = "strip (k_flush_strip)" if fcn["flush_strip"] else "plain (k_flush)"
+            delayed["flush_form"] = "k_flush_strip" if fcn["flush_strip"] else "k_flush"
+            delayed["gain_launches_from_column_panel"] = fcn["gain_from_panel"]
             delayed["gain_launches_paired"] = fcn["gain_pairs"]
             if want_cpu:
                 from oracle import binding as ob  # checker only
