@@ -43,7 +43,7 @@ SYMBOLS = [
     "ekf_dense_launch_info", "ekf_dense_tile_map", "ekf_batch_rank2_variant",
     "ekf_set_profiling", "ekf_get_profile", "ekf_batch_set_known_counts",
     "ekf_set_forms", "ekf_get_forms", "ekf_batch_set_forms", "ekf_batch_get_forms", "ekf_batch_form_counts",
-    "ekf_phase_trace",
+    "ekf_phase_trace", "ekf_test_raise_device_error",
 ]
 
 # ekf_form (include/ekfslam.h): launch structures the library may take where they apply; all exact forms are bit-identical
@@ -191,6 +191,7 @@ def load():
         "ekf_batch_get_forms": [h, C.POINTER(C.c_uint)],
         "ekf_batch_form_counts": [h, C.POINTER(C.c_longlong)],
         "ekf_phase_trace": [h, C.c_int, C.POINTER(C.c_longlong)],
+        "ekf_test_raise_device_error": [h],
         "ekf_get_profile": [h, _dp, C.POINTER(C.c_longlong)],
     }
     for name, argtypes in sig.items():

@@ -728,6 +728,12 @@ __global__ __launch_bounds__(256) void k_rank2v(double* __restrict__ sigma, cons
     }
 }
 
+// test hook: what await() does when its bound is hit
+__global__ void k_raise_device_error(PoolView pv) { report_device_error(pv, kErrHandoffTimeout); }
+void launch_raise_device_error(const PoolView& pv, hipStream_t s) {
+    hipLaunchKernelGGL(k_raise_device_error, dim3(1), dim3(1), 0, s, pv);
+}
+
 void launch_call_factors(const PoolView& pv, const CallSrc& src, double* U, double* V, int* cnt, double* state_out,
                          hipStream_t s) {
     if ((long long)pv.B * ((pv.ld + 255) / 256) >= 128)

@@ -513,6 +513,16 @@ ekf_status ekf_phase_trace(ekf_handle h, int enable, long long* out) {
     return EKF_OK;
 }
 
+ekf_status ekf_test_raise_device_error(ekf_handle h) {
+    if (!h) return fail(EKF_ERR_INVALID, "null handle");
+    Pool& P = h->pool;
+    EKFC(P.use());
+    ekf::launch_raise_device_error(P.pv, P.stream);
+    EKFC(checked_launch());
+    HIPC(hipStreamSynchronize(P.stream));   // (returns EKF_OK: the word is looked at by the NEXT entry)
+    return EKF_OK;
+}
+
 ekf_status ekf_set_profiling(ekf_handle h, int enable) {
     if (!h) return fail(EKF_ERR_INVALID, "null handle");
     Pool& P = h->pool;

@@ -152,7 +152,9 @@ struct PoolView {
 };
 enum : unsigned { kErrHandoffTimeout = 1u };
 __device__ __forceinline__ void report_device_error(const PoolView& pv, unsigned bit) {
-    __hip_atomic_fetch_or(pv.err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // a plain system-scope store (one bit is defined so far, so nothing can be lost): a read-modify-write on host memory
+    // would need PCIe atomics
+    __hip_atomic_store(pv.err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Layout of a single filter's association block -- [record | record | decisions] on the device, and its mirror in mapped
@@ -421,6 +423,7 @@ void launch_init(const PoolView& pv, hipStream_t s);
 // memory, then the sequence number (host layout: [record 32 B | seq 4 B | .. | decisions from byte 64])
 void launch_publish_assoc(const AssocRec* rec, const int* decisions, int J, char* host, unsigned seq, hipStream_t s);
 // prediction(): twist = imm (dtheta, dx) when twist_dev == nullptr, else twist_dev[b*2 + {0,1}]
+void launch_raise_device_error(const PoolView& pv, hipStream_t s);   // test hook (ekf_test_raise_device_error)
 void launch_predict(const PoolView& pv, const double* twist_dev, double dtheta, double dx, const Pending& pend,
                     hipStream_t s, double* pred_out = nullptr /* [B][2]: (a10, a20) of At, for the block cache */);
 // Delayed mode: one kernel per correction (no covariance stream); reads state from pv.state, writes the

@@ -185,6 +185,10 @@ ekf_status ekf_batch_get_touched(ekf_batch_handle hb, int* counts_out);
  * receives the stamps of the LAST call, [2][64] (slots: 0 start, 1 gathers issued, 2 prediction folded, then per
  * correction t at 3 + 5t: barrier passed, terms / panel update done, second barrier passed, gains done; 60 loop done). */
 ekf_status ekf_phase_trace(ekf_handle h, int enable, long long* out);
+/* Test hook of the device error word: a one-thread kernel raises it the way a kernel that gave up would (a bounded
+ * in-kernel hand-off that never arrived).  The call itself returns EKF_OK; every LATER entry point of the handle must
+ * fail with EKF_ERR_HIP (the word is sticky: results behind it are not to be used). */
+ekf_status ekf_test_raise_device_error(ekf_handle h);
 /* Blocks until every kernel queued on the handle's stream has finished. */
 ekf_status ekf_sync(ekf_handle h);
 /* Measurement hook (off by default): brackets every covariance-streaming launch (class 0: fused correction, rank-2

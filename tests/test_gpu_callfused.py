@@ -305,3 +305,20 @@ def test_two_handles_driven_from_two_host_threads(hip, oracle):
         assert np.array_equal(d, out["unknown"][3][t]), f"decisions of step {t}"
     assert np.array_equal(known, out["unknown"][2])
     assert_parity(out["unknown"][0], out["unknown"][1], o.state, o.cov, FP64_TOL, "unknown side, two threads")
+
+
+def test_device_error_word_fails_the_handle_and_only_that_handle(hip):
+    """A kernel that cannot go on (a bounded in-kernel hand-off that never arrives, ekf_callfused.hip await()) raises the
+    pool's device error word in mapped host memory instead of continuing with stale operands.  The test hook raises it the
+    same way: every later entry point of THAT handle fails with EKF_ERR_HIP (sticky), a second handle is untouched."""
+    f, g = hip.EKF_SLAM(150), hip.EKF_SLAM(150)
+    f.prediction((0.01, 0.05)); g.prediction((0.01, 0.05))
+    assert hip.load().ekf_test_raise_device_error(f._h) == 0          # the raising call itself returns EKF_OK
+    for call in (lambda: f.prediction((0.0, 0.01)), lambda: f.state, lambda: f.cov, lambda: f.sync(),
+                 lambda: f.data_association(np.array([[1.0, 0.2]]), np.zeros(150, dtype=np.uint8))):
+        with pytest.raises(hip.EkfError) as e:
+            call()
+        assert e.value.status == 3 and "device-side error" in str(e.value)   # EKF_ERR_HIP
+    g.prediction((0.0, 0.01))
+    assert np.isfinite(g.state).all() and g.getStateX() > 0.05
+    f.close(); g.close()
