@@ -85,7 +85,7 @@ class SimParams(C.Structure):
 class LidarParams(C.Structure):
     """ekf_lidar_params (include/ekfslam.h): the simulator's 2-D lidar."""
     _fields_ = [("n_beams", C.c_int), ("range_std", C.c_double), ("range_max", C.c_double),
-                ("border_width", C.c_double), ("tube_radius", C.c_double)]
+                ("border_width", C.c_double), ("tube_radius", C.c_double), ("model", C.c_int), ("range_min", C.c_double)]
 
 
 def default_lidar(**kw):

@@ -119,6 +119,8 @@ void ekf_default_lidar_params(ekf_lidar_params* out) {
     out->range_max = 3.5;        // tube_world.cpp:476
     out->border_width = 2.0;     // tube_param.yaml
     out->tube_radius = 0.0762;   // tube_param.yaml
+    out->model = 0;              // clean ray geometry (1: publishScan's own procedure)
+    out->range_min = 0.12;       // tube_world.cpp:475
 }
 
 static ekf::SimParams to_sim(const ekf_sim_params* sp) {
@@ -129,7 +131,7 @@ static ekf::SimParams to_sim(const ekf_sim_params* sp) {
 
 static bool lidar_ok(const ekf_lidar_params* lp) {
     return lp->n_beams >= 8 && lp->n_beams <= ekf::circles_max_beams() && lp->range_max > 0 && lp->border_width > 0 &&
-           lp->tube_radius > 0 && lp->range_std >= 0;
+           lp->tube_radius > 0 && lp->range_std >= 0 && (lp->model == 0 || (lp->model == 1 && lp->range_min > 0));
 }
 
 ekf_status ekf_batch_simulate_unknown_log(ekf_batch_handle hb, const ekf_sim_params* sp, const ekf_lidar_params* lidar,
@@ -161,7 +163,7 @@ ekf_status ekf_batch_simulate_unknown_log(ekf_batch_handle hb, const ekf_sim_par
         } else {
             ekf::launch_sim_unknown(p, B, n, T, jmax, d_world, P.ulog_twist, P.ulog_truth, nullptr, nullptr, true, P.stream);
             const ekf::LidarParams lp{lidar->n_beams, lidar->range_std, lidar->range_max, lidar->border_width,
-                                      lidar->tube_radius};
+                                      lidar->tube_radius, lidar->model, lidar->range_min};
             // scans are produced and consumed in chunks of whole steps (<= 256 MiB of ranges at a time)
             size_t steps_per_chunk = ((size_t)256 << 20) / (sizeof(double) * lp.n_beams * B);
             if (steps_per_chunk < 1) steps_per_chunk = 1;
@@ -233,7 +235,7 @@ ekf_status ekf_simulate_scans(int device, const ekf_sim_params* sp, const ekf_li
         if (n > 0) HIPC(hipMemcpy(d_world, world_xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(d_poses, poses, sizeof(double) * 3 * S, hipMemcpyHostToDevice));
         const ekf::LidarParams lp{lidar->n_beams, lidar->range_std, lidar->range_max, lidar->border_width,
-                                  lidar->tube_radius};
+                                  lidar->tube_radius, lidar->model, lidar->range_min};
         // B = S, t0 = step: scan s draws the noise stream of filter first_filter_id + s at that step
         ekf::launch_sim_scans(to_sim(sp), lp, S, n, S, step, d_world, d_poses, d_ranges, nullptr);
         HIPC(hipGetLastError());

@@ -261,10 +261,36 @@ __global__ __launch_bounds__(256) void k_sim_unknown_readings(SimParams p, int B
 }
 
 // One workgroup per scan: n_beams ranges of a 2-D lidar at poses[s] in a square walled world with n tubes of
-// one radius (publishScan, nurtlesim/src/tube_world.cpp:451-577, as clean ray geometry: nearest of the wall hit,
-// range_max and the first intersection with every tube), plus N(0, range_std) per beam (:571).
+// one radius (publishScan, nurtlesim/src/tube_world.cpp:451-577), plus N(0, range_std) per beam (:571).
+//   lp.model 0  clean ray geometry: nearest of the wall hit, range_max and the first intersection with every tube
+//   lp.model 1  publishScan's own procedure, step for step (scan_reference_beam below)
 // Host twin: synth.make_scans.  Candidate tubes (centre within range_max + radius) are compacted into LDS first.
 constexpr int kCandMax = 512;
+
+// what publishScan does for one tube and one beam (:518-565): the tube is looked at only inside a bearing window around it
+// (:526-552), and the hit is the nearer intersection of the LINE through the robot and the beam's end point with the tube's
+// circle, worked out in the tube's frame (getLineCircleIntersection, :420-450).  (tx, ty): the tube in the robot frame;
+// (start, end): its window; curr: the beam's angle; (x2, y2): the beam's end point at range_max.
+__device__ __forceinline__ double scan_reference_beam(double tx, double ty, double start, double end, double curr, double x2,
+                                                      double y2, double radius, double min_r) {
+    bool flag;
+    if (start > 0 && end < 0) flag = curr > start || curr < end;
+    else flag = curr > start && curr < end;
+    if (!flag) return min_r;
+    const double x1 = -tx, y1 = -ty;
+    const double xb = x2 - tx, yb = y2 - ty;
+    const double dx = xb - x1, dy = yb - y1;
+    const double dr = sqrt(dx * dx + dy * dy);
+    const double D = x1 * yb - xb * y1;
+    const double delta = radius * radius * (dr * dr) - D * D;
+    if (!(delta > 0)) return min_r;
+    const double sgn = dy < 0 ? -1.0 : 1.0, sq = sqrt(delta), dr2 = dr * dr;
+    const double ix1 = (D * dy + sgn * dx * sq) / dr2, iy1 = (-D * dx + fabs(dy) * sq) / dr2;
+    const double ix2 = (D * dy - sgn * dx * sq) / dr2, iy2 = (-D * dx - fabs(dy) * sq) / dr2;
+    const double d1 = sqrt((x1 - ix1) * (x1 - ix1) + (y1 - iy1) * (y1 - iy1));
+    const double d2 = sqrt((x1 - ix2) * (x1 - ix2) + (y1 - iy2) * (y1 - iy2));
+    return fmin(fmin(d1, d2), min_r);
+}
 __global__ __launch_bounds__(256) void k_sim_scans(SimParams p, LidarParams lp, int B, int n, int t0,
                                                    const double* __restrict__ world,
                                                    const double* __restrict__ poses, double* __restrict__ ranges) {
@@ -287,6 +313,43 @@ __global__ __launch_bounds__(256) void k_sim_scans(SimParams p, LidarParams lp, 
     __syncthreads();
     const int nc = n_cand;
     const double half = lp.border_width / 2.0, r2 = lp.tube_radius * lp.tube_radius;
+    if (lp.model == 1) {   // (uniform) publishScan's own procedure
+        __shared__ double cref[4 * kCandMax];   // per candidate: the tube in the robot frame and its bearing window
+        const double c0 = cos(th0), s0 = sin(th0);
+        const double window = 2.0 * atan2(lp.tube_radius, lp.range_min);   // :480
+        auto tube_terms = [&](double ex, double ey, double& tx, double& ty, double& st, double& en) {
+            tx = c0 * ex + s0 * ey; ty = -s0 * ex + c0 * ey;               // Ttw(world_tube), :520-521
+            const double tb = atan2(ty, tx);                                // :524
+            st = normalize_angle(tb - window / 2.0); en = normalize_angle(tb + window / 2.0);
+        };
+        if (nc <= kCandMax)
+            for (int k = tid; k < nc; k += 256)
+                tube_terms(-cand[2 * k], -cand[2 * k + 1], cref[4 * k], cref[4 * k + 1], cref[4 * k + 2], cref[4 * k + 3]);
+        __syncthreads();
+        const double res = 2.0 * 3.141592653589793 / (double)lp.n_beams;
+        for (int i = tid; i < lp.n_beams; i += 256) {
+            const double curr = normalize_angle(res * (double)i);           // :496
+            const double x2 = lp.range_max * cos(curr), y2 = lp.range_max * sin(curr);
+            const double x_dis = half - ox, y_dis = half - oy;
+            const double box = normalize_angle(res * (double)i + th0);      // :502
+            const double y_t = box < 0 ? -(lp.border_width - y_dis) : y_dis;
+            const double x_t = (box > 3.141592653589793 / 2.0 || box < -3.141592653589793 / 2.0) ? -(lp.border_width - x_dis) : x_dis;
+            double min_r = fmin(fmin(x_t / cos(box), y_t / sin(box)), lp.range_max);   // :512-516
+            if (nc <= kCandMax) {
+                for (int k = 0; k < nc; k++)
+                    min_r = scan_reference_beam(cref[4 * k], cref[4 * k + 1], cref[4 * k + 2], cref[4 * k + 3], curr, x2, y2,
+                                                lp.tube_radius, min_r);
+            } else {
+                for (int k = 0; k < n; k++) {
+                    double tx, ty, st, en;
+                    tube_terms(world[2 * k] - ox, world[2 * k + 1] - oy, tx, ty, st, en);
+                    min_r = scan_reference_beam(tx, ty, st, en, curr, x2, y2, lp.tube_radius, min_r);
+                }
+            }
+            ranges[(size_t)sidx * lp.n_beams + i] = min_r + lp.range_std * normal01(p.seed, fid, step, KIND_SCAN, (unsigned long long)i);
+        }
+        return;
+    }
     for (int i = tid; i < lp.n_beams; i += 256) {
         const double ang = 2.0 * 3.141592653589793 * (double)i / (double)lp.n_beams;
         const double th = th0 + ang;

@@ -17,6 +17,8 @@ struct SimParams {  // mirrors ekf_sim_params of include/ekfslam.h
 struct LidarParams {  // mirrors ekf_lidar_params of include/ekfslam.h
     int n_beams;
     double range_std, range_max, border_width, tube_radius;
+    int model;          // 0 clean ray geometry, 1 publishScan's bearing window + line-circle procedure
+    double range_min;
 };
 
 // unknown-association inputs: twist/truth as launch_sim, then per (step, filter) up to jmax shuffled readings

@@ -343,14 +343,69 @@ WORLD_BORDER_WIDTH = 2.0
 KIND_SCAN = 6
 
 
+def _normalize_angle(a):
+    """rigid2d::normalize_angle (rigid2d.cpp:336-345): double fmod, range (-pi, pi]"""
+    two_pi = 2.0 * np.pi
+    a = np.fmod(np.fmod(a, two_pi) + two_pi, two_pi)
+    return np.where(a > np.pi, a - two_pi, a)
+
+
+def _scans_reference_model(poses, world, n_beams, range_max, border, tube_radius, range_min):
+    """publishScan's own procedure, step for step (nurtlesim/src/tube_world.cpp:496-570), noise-free ranges [S, n_beams]."""
+    S = len(poses)
+    res = 2.0 * np.pi / n_beams                                    # :462
+    i = np.arange(n_beams, dtype=np.float64)
+    theta, px, py = poses[:, 0:1], poses[:, 1:2], poses[:, 2:3]
+    window = 2.0 * np.arctan2(tube_radius, range_min)              # :480 largest_tube_scan_theta
+    curr = np.broadcast_to(_normalize_angle(res * i)[None, :], (S, n_beams))   # :496
+    x2, y2 = range_max * np.cos(curr), range_max * np.sin(curr)    # :497-498 (min_r = 3.5 there)
+    x_dis, y_dis = border / 2.0 - px, border / 2.0 - py            # :460-461
+    box = _normalize_angle(res * i[None, :] + theta)               # :502
+    y_t = np.where(box < 0, -(border - y_dis), y_dis)              # :503-505
+    x_t = np.where((box > np.pi / 2.0) | (box < -np.pi / 2.0), -(border - x_dis), x_dis)   # :507-509
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.minimum(x_t / np.cos(box), y_t / np.sin(box))      # :512
+    min_r = np.minimum(r, range_max)                               # :516
+    c, s_ = np.cos(theta), np.sin(theta)
+    for (wx, wy) in world:                                         # :518-566
+        ex, ey = wx - px, wy - py
+        tx, ty = c * ex + s_ * ey, -s_ * ex + c * ey               # Ttw(world_tube), :520-521
+        tb = np.arctan2(ty, tx)                                    # :524
+        start, end = _normalize_angle(tb - window / 2.0), _normalize_angle(tb + window / 2.0)   # :526-527
+        inside = (curr > start) & (curr < end)
+        flag = np.where((start > 0) & (end < 0), (curr > start) | (curr < end), inside)        # :530-552
+        # getLineCircleIntersection (:420-450) in the tube's frame: turtle at (-tx, -ty), beam end at (x2 - tx, y2 - ty)
+        x1, y1 = -tx, -ty
+        xb, yb = x2 - tx, y2 - ty
+        dx, dy = xb - x1, yb - y1
+        dr = np.sqrt(dx ** 2 + dy ** 2)
+        D = x1 * yb - xb * y1
+        delta = tube_radius ** 2 * dr ** 2 - D ** 2
+        hit = flag & (delta > 0)
+        sq = np.sqrt(np.where(hit, delta, 0.0))
+        sgn = np.where(dy < 0, -1.0, 1.0)
+        ix1, iy1 = (D * dy + sgn * dx * sq) / dr ** 2, (-D * dx + np.abs(dy) * sq) / dr ** 2
+        ix2, iy2 = (D * dy - sgn * dx * sq) / dr ** 2, (-D * dx - np.abs(dy) * sq) / dr ** 2
+        d1 = np.sqrt((x1 - ix1) ** 2 + (y1 - iy1) ** 2)
+        d2 = np.sqrt((x1 - ix2) ** 2 + (y1 - iy2) ** 2)
+        min_r = np.where(hit, np.minimum(np.minimum(d1, d2), min_r), min_r)   # :563-564
+    return min_r
+
+
 def make_scans(poses, world=None, n_beams=360, seed=7, range_std=0.005, range_max=3.5,
-               border=WORLD_BORDER_WIDTH, tube_radius=TUBE_RADIUS, fid=None, step=0):
+               border=WORLD_BORDER_WIDTH, tube_radius=TUBE_RADIUS, fid=None, step=0, model=0, range_min=0.12):
     """poses [S, 3] = (theta, x, y) -> ranges [S, n_beams] (float64), deterministic in (seed, fid, step, beam);
-    fid defaults to the scan id.  Device twin: k_sim_scans (ekf_sim.hip)."""
+    fid defaults to the scan id.  Device twin: k_sim_scans (ekf_sim.hip).  model 0: clean ray geometry; model 1:
+    publishScan's own bearing-window + line-circle procedure (ekf_lidar_params.model, include/ekfslam.h)."""
     poses = np.asarray(poses, dtype=np.float64).reshape(-1, 3)
     if world is None:
         world = np.stack([TUBE_X, TUBE_Y], axis=1)
     S = len(poses)
+    if model == 1:
+        r = _scans_reference_model(poses, np.asarray(world, dtype=np.float64), n_beams, range_max, border, tube_radius, range_min)
+        sid = (np.arange(S, dtype=np.uint64) if fid is None else np.asarray(fid, dtype=np.uint64).reshape(S))[:, None]
+        stp = np.broadcast_to(np.asarray(step, dtype=np.uint64).reshape(-1, 1), (S, 1))
+        return r + range_std * normal01(seed, sid, stp, KIND_SCAN, np.arange(n_beams, dtype=np.uint64)[None, :])
     ang = 2.0 * np.pi * np.arange(n_beams) / n_beams
     th = poses[:, 0:1] + ang[None, :]                       # world-frame beam direction [S, nb]
     dx, dy = np.cos(th), np.sin(th)

@@ -319,6 +319,14 @@ typedef struct ekf_lidar_params {
     double range_max;     /* 3.5, tube_world.cpp:476                                      */
     double border_width;  /* tube_param.yaml: world_border_width 2.0 (square wall)        */
     double tube_radius;   /* tube_param.yaml: tube_radius 0.0762                          */
+    /* 0 (default): clean ray geometry -- nearest of the wall hit, range_max and the first intersection of the beam with
+     * every tube.  1: publishScan's own procedure, step for step (tube_world.cpp:496-570): a tube is looked at only by the
+     * beams inside a bearing window of 2 atan2(radius, range_min) around it (:503,533-562), and the hit is the nearer of
+     * the two intersections of the LINE through the robot and the beam's end point with the tube's circle
+     * (getLineCircleIntersection, :420-450).  The two agree to rounding wherever no tube is closer than
+     * radius / sin(atan2(radius, range_min)) = 0.142 m to the lidar (tests/test_host.py); closer tubes the window clips. */
+    int model;
+    double range_min;     /* 0.12, tube_world.cpp:475 (model 1: the bearing window)      */
 } ekf_lidar_params;
 void ekf_default_lidar_params(ekf_lidar_params* out);
 /* Unknown-association inputs generated ON THE DEVICE for every filter of the batch (replaces any

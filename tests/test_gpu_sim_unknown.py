@@ -61,6 +61,28 @@ def test_device_scans_many_tubes_and_other_beam_counts(hip):
     assert np.abs(dev - host).max() < 1e-12
 
 
+def test_device_scans_reference_model_equals_host_twin(hip):
+    """ekf_lidar_params.model 1 (publishScan's own bearing-window + line-circle procedure, tube_world.cpp:496-570) on the
+    device against its host twin: the reference's ten tubes, a crowded map with > 512 tubes in reach (whole-map walk), poses
+    next to tubes (where the window clips and the models differ)."""
+    rng = np.random.default_rng(8)
+    S = 48
+    poses = np.stack([rng.uniform(-np.pi, np.pi, S), rng.uniform(-0.8, 0.8, S), rng.uniform(-0.8, 0.8, S)], axis=1)
+    world = np.stack([synth.TUBE_X, synth.TUBE_Y], axis=1)
+    lp = hip.default_lidar(model=1)
+    dev = hip.simulate_scans(poses, world, seed=3, first_filter_id=7, step=2, lidar=lp)
+    host = synth.make_scans(poses, world, seed=3, fid=7 + np.arange(S), step=2, model=1)
+    assert np.abs(dev - host).max() < 1e-12
+    clean = synth.make_scans(poses, world, seed=3, fid=7 + np.arange(S), step=2, model=0)
+    assert 0 < (np.abs(host - clean) > 1e-9).mean() < 0.05     # the two models differ on a few beams next to tubes only
+    big = synth.make_world(700, 3.0, 0.15, 9, use_reference_tubes=False)
+    p3 = np.array([[0.3, 0.1, -0.2], [2.0, -1.0, 1.0], [-1.0, 2.5, 2.5]])
+    lp = hip.default_lidar(n_beams=500, border_width=8.0, range_max=4.5, tube_radius=0.05, range_std=0.002, model=1)
+    dev = hip.simulate_scans(p3, big, seed=1, lidar=lp)
+    host = synth.make_scans(p3, big, n_beams=500, seed=1, range_std=0.002, range_max=4.5, border=8.0, tube_radius=0.05, model=1)
+    assert np.abs(dev - host).max() < 1e-12
+
+
 def test_lidar_log_matches_checkers_and_filters_it(hip, oracle):
     """scans -> circles -> measurements stay on the device; every sampled (step, filter) must equal the host scan twin
     pushed through the circle checker, and the run over that log must equal the CPU filter."""

@@ -151,3 +151,33 @@ def test_scan_generator_addressing():
     tube = np.array([[1.0, 0.0]])
     r = synth.make_scans(poses[:1], world=tube, range_std=0.0, border=10.0)[0]
     assert abs(r[0] - (1.0 - synth.TUBE_RADIUS)) < 1e-12 and r[180] == 3.5
+
+
+def test_reference_scan_model_agrees_with_ray_geometry_away_from_tubes():
+    """ekf_lidar_params.model 1 = publishScan's own procedure (nurtlesim/src/tube_world.cpp:496-570: a bearing window of
+    2 atan2(radius, range_min) around every tube, then the nearer intersection of the LINE through the robot and the beam's end
+    point with the tube's circle) against model 0 (clean ray geometry): the same ranges to rounding for every pose that has
+    no tube closer than radius / sin(atan2(radius, range_min)) = 0.142 m -- closer tubes subtend more than the window and the
+    reference clips them, which is the one place where the two differ (shown on a tube 0.10 m away)."""
+    from ekf_slam_ml_amd import synth
+    rng = np.random.default_rng(12)
+    S = 300
+    poses = np.stack([rng.uniform(-np.pi, np.pi, S), rng.uniform(-0.8, 0.8, S), rng.uniform(-0.8, 0.8, S)], axis=1)
+    world = np.stack([synth.TUBE_X, synth.TUBE_Y], axis=1)
+    near = np.sqrt(((poses[:, None, 1:] - world[None]) ** 2).sum(-1)).min(axis=1)
+    far = near >= 0.145
+    a = synth.make_scans(poses, world, range_std=0.0, model=0)
+    b = synth.make_scans(poses, world, range_std=0.0, model=1)
+    assert far.sum() > 200 and np.abs(a[far] - b[far]).max() < 1e-12
+    assert (a[far] < 1.0).mean() > 0.2                       # walls and tubes are really hit
+    # both models draw the same noise (same (seed, filter, step, beam) addressing)
+    n1 = synth.make_scans(poses[far][:3], world, seed=5, model=1) - b[far][:3]
+    n0 = synth.make_scans(poses[far][:3], world, seed=5, model=0) - a[far][:3]
+    assert np.abs(n1 - n0).max() < 1e-12 and np.abs(n1).max() > 1e-3
+    # a tube 0.10 m ahead: it subtends +-49.6 deg, the window is +-32.4 deg -> the reference sees the wall beyond its rim
+    tube = np.array([[0.10, 0.0]])
+    p0 = np.zeros((1, 3))
+    c = synth.make_scans(p0, tube, range_std=0.0, model=0, border=10.0)[0]
+    r = synth.make_scans(p0, tube, range_std=0.0, model=1, border=10.0)[0]
+    assert abs(c[0] - (0.10 - synth.TUBE_RADIUS)) < 1e-12 and abs(r[0] - c[0]) < 1e-12      # straight ahead: both hit
+    assert c[40] < 0.2 and r[40] == 3.5                                                    # 40 deg: inside the rim, outside the window
