@@ -458,10 +458,19 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
             EKFC(P.ensure_blk_cache());
             if (Nstep > 3 + 2 * kc_max) kc_max = (Nstep - 3) / 2;
             if (P.pend_count + 2 * jmax > P.pend_cap) EKFC(timed_flush());
+            // pairs of earlier steps pending: their part of what this step's gains need is rebuilt ONCE, for the landmarks
+            // the readings are guessed to match (EKF_FORM_STEP_SPECULATE; ekf_stepfused.hip, k_pool_step_spec)
+            const bool speculate = P.step_speculate && P.pend_count > 0;
+            if (speculate) {
+                EKFC(P.ensure_spec());
+                ekf::launch_pool_step_spec(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
+                                           P.pending(), P.spec, P.specw, P.stream);
+            }
             ekf::launch_pool_step_unknown_delayed(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,
                                                   P.active_prefix ? 3 + 2 * P.touched_hwm : P.pv.N,
                                                   P.ulog_assoc + (size_t)t * B * jmax, P.pending(), P.corr_counter, P.cf_cnt,
-                                                  P.blk_cache, P.cf_pred, P.stream);
+                                                  P.blk_cache, P.cf_pred, P.stream, speculate ? P.spec : nullptr,
+                                                  speculate ? P.specw : nullptr);
             P.pend_count += 2 * jmax;
             P.form_counts[5]++;
             smax = 0;  // the step is done

@@ -585,8 +585,19 @@ void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int*
 void launch_pool_step_unknown_delayed(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                                       int* assoc_out, const Pending& pend, unsigned long long* corr_counter, int* cnt_scratch,
                                       double* blocks, const double* pred /* [B][2] (a10, a20) of the step's prediction */,
-                                      hipStream_t s);
+                                      hipStream_t s, const double* spec = nullptr, const int* specw = nullptr);
 int step_pending_pairs_max();   // pairs a filter can carry between flushes in that mode
+// Delayed mode, in front of launch_pool_step_unknown_delayed when pairs of earlier steps are pending: the "old part" of
+// what the step's gains will need.  A reading's gain needs Sigma(r, c5) and Sigma(c5, r) of its winner as they stand now =
+// stored entries minus ALL pending pairs, i.e. a pass over the whole pending store per reading.  The winner is decided
+// reading by reading, but the old pairs' part of those rows / columns does not depend on this step's earlier readings:
+// this launch GUESSES each reading's winner (the landmark nearest to where the reading lands from the step's pose),
+// rebuilds "stored minus the old pairs" once for the <= kCallV guessed landmarks and for the pose indices, in the order the
+// step kernel would take, and leaves it in spec [B][spec_rows()][ld] with the guesses in specw [B][kCallV].  The step kernel
+// uses a guess that matches its decision and rebuilds from scratch otherwise: bit-identical either way.
+int spec_rows();
+void launch_pool_step_spec(const PoolView& pv, const double* meas, const int* count, int jmax, const Pending& pend,
+                           double* spec, int* specw, hipStream_t s);
 
 int max_pending();  // capacity limit of the delayed-update factor store (rows of U / V per filter)
 void launch_gather_poses(const PoolView& pv, double* out, hipStream_t s);

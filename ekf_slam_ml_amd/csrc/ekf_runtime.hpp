@@ -209,6 +209,17 @@ struct Pool {
     double* call_in = nullptr;     // single filter: [2n] sensor_reading | [1 + n] ints: V, visible landmarks
     double* cf_pred = nullptr;     // [B][2] (A10, A20) of a prediction folded into the call
     double* blk_cache = nullptr;   // [B][25][n] pools' step-fused association: every landmark's current 5 x 5 block
+    // pools' delayed association: the old part of a step's gains for the guessed winners (ekf_kernels.hpp, launch_pool_step_spec)
+    double* spec = nullptr;        // [B][spec_rows()][ld]
+    int* specw = nullptr;          // [B][kCallV]
+    int step_speculate = 1;        // EKF_FORM_STEP_SPECULATE
+    ekf_status ensure_spec() {
+        if (!spec) {
+            EKFC(dalloc(&spec, (size_t)pv.B * ekf::spec_rows() * pv.ld));
+            EKFC(dalloc(&specw, (size_t)pv.B * ekf::kCallV));
+        }
+        return EKF_OK;
+    }
     ekf_status ensure_blk_cache() {
         if (!blk_cache) EKFC(dalloc(&blk_cache, (size_t)pv.B * 25 * (pv.n > 0 ? pv.n : 1)));
         return EKF_OK;
@@ -253,6 +264,7 @@ struct Pool {
         step_fused = (f & EKF_FORM_STEP_FUSED) ? ((f & EKF_FORM_STEP_SPLIT_PASS) ? 1 : 2) : 0;
         delayed_pair = (f & EKF_FORM_DELAYED_PAIR) ? 1 : 0;
         column_panel = (f & EKF_FORM_COLUMN_PANEL) ? ((f & EKF_FORM_COLUMN_PANEL_ONE_SLOT) ? 2 : 1) : 0;
+        step_speculate = (f & EKF_FORM_STEP_SPECULATE) ? 1 : 0;
         tuning.row_packing = (f & EKF_FORM_ROW_PACKING) ? 1 : 0;
         tuning.strip_flush = (f & EKF_FORM_STRIP_FLUSH_ALWAYS) ? 2 : (f & EKF_FORM_STRIP_FLUSH) ? 1 : 0;
         return EKF_OK;
@@ -514,7 +526,7 @@ struct Pool {
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
                         phase_trace, terms2, scores2, blk_cache, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred,
-                        colp, lmslot, plan_list, uvc};
+                        colp, lmslot, plan_list, uvc, spec, specw};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();

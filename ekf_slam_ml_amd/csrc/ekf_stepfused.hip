@@ -24,6 +24,7 @@
 namespace ekf {
 
 constexpr int kStepThreads = 512;
+constexpr int kSpecRows = 4 * kCallV + 6;   // k_pool_step_spec: per guessed landmark 2 column + 2 row vectors, then 3 + 3 for the pose
 constexpr int kStepPendingPairs = 64;   // delayed mode: pairs a filter can carry between flushes (= max_pending() / 2)
 
 // DELAYED (ekf_batch_set_update_mode(k > 0), SURVEY.md section 8(f) f2 applied to data_association): the pairs of a step are
@@ -39,7 +40,9 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
                                                                     unsigned long long* __restrict__ corr_counter,
                                                                     int* __restrict__ cnt_out, int zero_upto, int p0,
                                                                     int pair_rows, double* __restrict__ blocks_all,
-                                                                    const double* __restrict__ pred, int sym) {
+                                                                    const double* __restrict__ pred, int sym,
+                                                                    const double* __restrict__ spec_all,
+                                                                    const int* __restrict__ specw_all) {
     constexpr int kPairs = DELAYED ? kStepPendingPairs : kCallV;
     // cnt_out == nullptr: the final pass runs here (one workgroup streams its filter's covariance).  Otherwise the step
     // ends with the pairs in Uall / Vall (rows beyond the filter's pair count zero-filled up to `zero_upto` pairs) and
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
 
     __shared__ double sh_d[kStepThreads / 64];
     __shared__ int sh_i[kStepThreads / 64];
-    __shared__ int sh_M, sh_lm, sh_new, sh_applied;
+    __shared__ int sh_M, sh_lm, sh_new, sh_applied, sh_slot;
     __shared__ double sh_H[10], sh_Si[4], sh_nu[2];
     __shared__ double2_t sh_K[32][kCallV];   // K_v of a row block of the final pass
     // pending pairs at the five indices c5 of the landmark in hand: [v][0..2] = pose rows / columns (kept up to date as
@@ -246,6 +249,10 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
             sh_new = is_new;
             out[j] = sh_lm;
             if (active) sh_applied++;
+            int slot = -1;   // the launch in front guessed this winner (k_pool_step_spec): its old part is ready
+            if (DELAYED && spec_all && active && !is_new)
+                for (int q = 0; q < kCallV; q++) if (specw_all[(size_t)b * kCallV + q] == idx) { slot = q; break; }
+            sh_slot = slot;
         }
         __syncthreads();
         const int lm = sh_lm;
@@ -295,9 +302,29 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
                 // sym (the symmetric option of the delayed mode, uniform): Sigma H^T is taken as (H Sigma)^T -- no column
                 // gather, no read of the U half of the pending pairs
                 double p[5], g[5];
-                if (!sym) gather_row5(Sg + (size_t)r * ld, lm, p);   // column gather (Sigma * H^T reads columns): three loads
+                const int slot = DELAYED ? sh_slot : -1;
+                int v = 0;
+                if (slot >= 0) {
+                    // guessed right: "stored minus the pairs of earlier steps" for this landmark and the pose indices was
+                    // rebuilt once for the whole step by k_pool_step_spec, in this loop's own order -- ten coalesced loads
+                    // instead of the column sectors, the rows and p0 x 4 factor rows; only this step's pairs are left to fold
+                    const double* sp = spec_all + (size_t)b * kSpecRows * ld;
 #pragma unroll
-                for (int k = 0; k < 5; k++) g[k] = Sg[(size_t)idx5(k, lm) * ld + r];   // row gather (H * Sigma reads rows)
+                    for (int k = 0; k < 3; k++) {
+                        if (!sym) p[k] = sp[(size_t)(4 * kCallV + k) * ld + r];
+                        g[k] = sp[(size_t)(4 * kCallV + 3 + k) * ld + r];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        if (!sym) p[3 + q] = sp[(size_t)(4 * slot + q) * ld + r];
+                        g[3 + q] = sp[(size_t)(4 * slot + 2 + q) * ld + r];
+                    }
+                    v = p0;
+                } else {
+                    if (!sym) gather_row5(Sg + (size_t)r * ld, lm, p);   // column gather (Sigma * H^T reads columns): three loads
+#pragma unroll
+                    for (int k = 0; k < 5; k++) g[k] = Sg[(size_t)idx5(k, lm) * ld + r];   // row gather (H * Sigma reads rows)
+                }
                 // ... as they stand now: minus the pending pairs, in order (four pairs' values requested together)
                 auto fold_rc = [&](int v, const double (&f)[4]) {
 #pragma unroll
@@ -310,7 +337,6 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
                     if (!sym) { f[0] = Ub[(size_t)(2 * v) * ld + r]; f[1] = Ub[(size_t)(2 * v + 1) * ld + r]; }
                     f[2] = Vb[(size_t)(2 * v) * ld + r]; f[3] = Vb[(size_t)(2 * v + 1) * ld + r];
                 };
-                int v = 0;
                 for (; v + 4 <= pc; v += 4) {
                     double f[4][4];
 #pragma unroll
@@ -444,19 +470,200 @@ __global__ __launch_bounds__(kStepThreads) void k_pool_step_unknown(PoolView pv,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The old part of a delayed step's gains, once per step (see launch_pool_step_spec in ekf_kernels.hpp).
+// grid (ceil(ld / 512), B), 256 threads, a lane owns the indices r, r + 1 (k_gain_delayed_pair's layout).  Every workgroup
+// repeats the guess (a reduction over the filter's landmarks: cheap) and gathers the old pairs' entries at the guessed
+// indices; the lanes then stream the old pairs ONCE for all guesses.  Arithmetic: the step kernel's fold_rc, pair by pair
+// in the same order, so that what it continues from is what it would have had.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pool_step_spec(PoolView pv, const double* __restrict__ meas_all,
+                                                        const int* __restrict__ count, int jmax, const double* __restrict__ Uall,
+                                                        const double* __restrict__ Vall, int p0, int pair_rows, int sym,
+                                                        double* __restrict__ spec_all, int* __restrict__ specw_all) {
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int n = pv.n, ld = pv.ld, N = pv.N;
+    const int J = count ? count[b] : jmax;
+    int* wout = specw_all + (size_t)b * kCallV;
+    if (J <= 0 || p0 <= 0) {   // (uniform) nothing to prepare
+        if (blockIdx.x == 0 && tid < kCallV) wout[tid] = -1;
+        return;
+    }
+    const double* Sg = pv.sigma + (size_t)b * pv.sigma_stride;
+    const double* st = pv.state + (size_t)b * ld;
+    const double* Ub = Uall + (size_t)b * pair_rows * ld;
+    const double* Vb = Vall + (size_t)b * pair_rows * ld;
+    const double* meas = meas_all + (size_t)b * jmax * 2;
+    const int M = min(pv.assoc[b].known_count, n);
+    __shared__ double sh_d[4][kCallV];
+    __shared__ int sh_i[4][kCallV];
+    __shared__ int sh_w[kCallV];
+    __shared__ double sh_Kp[kStepPendingPairs][3][2], sh_Gp[kStepPendingPairs][3][2];            // old pairs at the pose indices
+    __shared__ double sh_Kw[kStepPendingPairs][kCallV][2][2], sh_Gw[kStepPendingPairs][kCallV][2][2];   // ... at the guessed landmarks
+    // ---- the guess: reading j lands at pose (+) reading; its landmark is the nearest one (the decision itself is the step
+    // kernel's: a wrong guess costs it the rebuild it would have done anyway) ----
+    const double theta = st[0], x = st[1], y = st[2];
+    const double c = cos(theta), sn = sin(theta);
+    double bd[kCallV];
+    int bi[kCallV];
+#pragma unroll
+    for (int j = 0; j < kCallV; j++) { bd[j] = __builtin_huge_val(); bi[j] = -1; }
+    for (int i = tid; i < M; i += 256) {
+        const double lx = st[2 * i + 3], ly = st[2 * i + 4];
+#pragma unroll
+        for (int j = 0; j < kCallV; j++) {
+            if (j < J) {
+                const double wx = x + (meas[2 * j] * c - meas[2 * j + 1] * sn), wy = y + (meas[2 * j] * sn + meas[2 * j + 1] * c);
+                const double d = (lx - wx) * (lx - wx) + (ly - wy) * (ly - wy);
+                if (d < bd[j]) { bd[j] = d; bi[j] = i; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kCallV; j++) {
+        double rd = bd[j];
+        int ri = bi[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_down(rd, off, kWave);
+            const int oi = __shfl_down(ri, off, kWave);
+            if (od < rd || (od == rd && oi >= 0 && (ri < 0 || oi < ri))) { rd = od; ri = oi; }
+        }
+        if (lane == 0) { sh_d[tid >> 6][j] = rd; sh_i[tid >> 6][j] = ri; }
+    }
+    __syncthreads();
+    if (tid < kCallV) {
+        double rd = sh_d[0][tid];
+        int ri = sh_i[0][tid];
+        for (int w = 1; w < 4; w++)
+            if (sh_d[w][tid] < rd || (sh_d[w][tid] == rd && sh_i[w][tid] >= 0 && (ri < 0 || sh_i[w][tid] < ri))) { rd = sh_d[w][tid]; ri = sh_i[w][tid]; }
+        sh_w[tid] = tid < J ? ri : -1;
+    }
+    __syncthreads();
+    if (tid == 0) {   // one slot per distinct landmark
+        for (int j = 1; j < kCallV; j++)
+            for (int q = 0; q < j; q++)
+                if (sh_w[j] >= 0 && sh_w[j] == sh_w[q]) { sh_w[j] = -1; break; }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < kCallV) wout[tid] = sh_w[tid];
+    // ---- the old pairs' entries at the pose indices and at the guessed landmarks' indices ----
+    for (int e = tid; e < p0 * 12; e += 256) {
+        const int v = e / 12, q = (e % 12) >> 2, h = (e >> 1) & 1, uvsel = e & 1;
+        if (uvsel == 0) sh_Kp[v][q][h] = Ub[(size_t)(2 * v + h) * ld + q];
+        else sh_Gp[v][q][h] = Vb[(size_t)(2 * v + h) * ld + q];
+    }
+    for (int e = tid; e < p0 * kCallV * 8; e += 256) {
+        const int v = e / (kCallV * 8), rest = e - v * (kCallV * 8);
+        const int s = rest >> 3, q = (rest >> 2) & 1, h = (rest >> 1) & 1, uvsel = rest & 1;
+        const int lm = sh_w[s];
+        double val = 0.0;
+        if (lm >= 0) val = (uvsel == 0 ? Ub : Vb)[(size_t)(2 * v + h) * ld + 3 + 2 * lm + q];
+        if (uvsel == 0) sh_Kw[v][s][q][h] = val; else sh_Gw[v][s][q][h] = val;
+    }
+    __syncthreads();
+    // ---- stream the old pairs once: r, r + 1 per lane ----
+    const int r = 2 * (blockIdx.x * 256 + tid);
+    if (r >= ld) return;
+    double* sp = spec_all + (size_t)b * kSpecRows * ld;
+    const double2_t zero2 = {0.0, 0.0};
+    const bool live = r < N, two = r + 1 < N;
+    double2_t pp[3], gp[3], pw[kCallV][2], gw[kCallV][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pp[k] = zero2; gp[k] = zero2; }
+#pragma unroll
+    for (int s = 0; s < kCallV; s++) { pw[s][0] = pw[s][1] = gw[s][0] = gw[s][1] = zero2; }
+    if (live) {
+        const double* rw0 = Sg + (size_t)r * ld;
+        const double* rw1 = Sg + (size_t)(two ? r + 1 : r) * ld;
+        if (!sym) {
+            const D2u a0 = *reinterpret_cast<const D2u*>(rw0), a1 = *reinterpret_cast<const D2u*>(rw1);
+            pp[0] = double2_t{a0.x, a1.x}; pp[1] = double2_t{a0.y, a1.y}; pp[2] = double2_t{rw0[2], rw1[2]};
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) gp[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)k * ld + r);
+#pragma unroll
+        for (int s = 0; s < kCallV; s++) {
+            const int lm = sh_w[s];
+            if (lm < 0) continue;   // (uniform)
+            const size_t cl = 3 + 2 * (size_t)lm;
+            if (!sym) {
+                const D2u b0 = *reinterpret_cast<const D2u*>(rw0 + cl), b1 = *reinterpret_cast<const D2u*>(rw1 + cl);
+                pw[s][0] = double2_t{b0.x, b1.x}; pw[s][1] = double2_t{b0.y, b1.y};
+            }
+            gw[s][0] = *reinterpret_cast<const double2_t*>(Sg + cl * ld + r);
+            gw[s][1] = *reinterpret_cast<const double2_t*>(Sg + (cl + 1) * ld + r);
+        }
+        for (int v = 0; v < p0; v++) {
+            double2_t f0 = zero2, f1 = zero2;
+            if (!sym) {
+                f0 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(2 * v) * ld + r);
+                f1 = *reinterpret_cast<const double2_t*>(Ub + (size_t)(2 * v + 1) * ld + r);
+            }
+            const double2_t f2 = *reinterpret_cast<const double2_t*>(Vb + (size_t)(2 * v) * ld + r);
+            const double2_t f3 = *reinterpret_cast<const double2_t*>(Vb + (size_t)(2 * v + 1) * ld + r);
+            // (the step kernel's fold_rc, component by component)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (!sym) {
+                    pp[k].x = pp[k].x - (f0.x * sh_Gp[v][k][0] + f1.x * sh_Gp[v][k][1]);
+                    pp[k].y = pp[k].y - (f0.y * sh_Gp[v][k][0] + f1.y * sh_Gp[v][k][1]);
+                }
+                gp[k].x = gp[k].x - (sh_Kp[v][k][0] * f2.x + sh_Kp[v][k][1] * f3.x);
+                gp[k].y = gp[k].y - (sh_Kp[v][k][0] * f2.y + sh_Kp[v][k][1] * f3.y);
+            }
+#pragma unroll
+            for (int s = 0; s < kCallV; s++) {
+                if (sh_w[s] < 0) continue;   // (uniform)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    if (!sym) {
+                        pw[s][q].x = pw[s][q].x - (f0.x * sh_Gw[v][s][q][0] + f1.x * sh_Gw[v][s][q][1]);
+                        pw[s][q].y = pw[s][q].y - (f0.y * sh_Gw[v][s][q][0] + f1.y * sh_Gw[v][s][q][1]);
+                    }
+                    gw[s][q].x = gw[s][q].x - (sh_Kw[v][s][q][0] * f2.x + sh_Kw[v][s][q][1] * f3.x);
+                    gw[s][q].y = gw[s][q].y - (sh_Kw[v][s][q][0] * f2.y + sh_Kw[v][s][q][1] * f3.y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        *reinterpret_cast<double2_t*>(sp + (size_t)(4 * kCallV + k) * ld + r) = pp[k];
+        *reinterpret_cast<double2_t*>(sp + (size_t)(4 * kCallV + 3 + k) * ld + r) = gp[k];
+    }
+#pragma unroll
+    for (int s = 0; s < kCallV; s++) {
+        if (sh_w[s] < 0) continue;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            *reinterpret_cast<double2_t*>(sp + (size_t)(4 * s + q) * ld + r) = pw[s][q];
+            *reinterpret_cast<double2_t*>(sp + (size_t)(4 * s + 2 + q) * ld + r) = gw[s][q];
+        }
+    }
+}
+
+int spec_rows() { return kSpecRows; }
+
+void launch_pool_step_spec(const PoolView& pv, const double* meas, const int* count, int jmax, const Pending& pend,
+                           double* spec, int* specw, hipStream_t s) {
+    hipLaunchKernelGGL(k_pool_step_spec, dim3((pv.ld / 2 + 255) / 256, pv.B), dim3(256), 0, s, pv, meas, count, jmax, pend.U,
+                       pend.V, pend.count / 2, pend.cap, pend.symmetric != 0, spec, specw);
+}
+
 void launch_pool_step_unknown(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                               int* assoc_out, double* U, double* V, unsigned long long* corr_counter, hipStream_t s,
                               int* cnt_out, int zero_upto, double* blocks) {
     hipLaunchKernelGGL(k_pool_step_unknown<false>, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
-                       assoc_out, U, V, corr_counter, cnt_out, zero_upto, 0, 2 * kCallV, blocks, nullptr, 0);
+                       assoc_out, U, V, corr_counter, cnt_out, zero_upto, 0, 2 * kCallV, blocks, nullptr, 0, nullptr, nullptr);
 }
 
 void launch_pool_step_unknown_delayed(const PoolView& pv, const double* meas, const int* count, int jmax, int min_active,
                                       int* assoc_out, const Pending& pend, unsigned long long* corr_counter, int* cnt_scratch,
-                                      double* blocks, const double* pred, hipStream_t s) {
+                                      double* blocks, const double* pred, hipStream_t s, const double* spec, const int* specw) {
     hipLaunchKernelGGL(k_pool_step_unknown<true>, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
                        assoc_out, pend.U, pend.V, corr_counter, cnt_scratch, jmax, pend.count / 2, pend.cap, blocks, pred,
-                       pend.symmetric != 0);
+                       pend.symmetric != 0, pend.count > 0 ? spec : nullptr, specw);
 }
 
 int step_pending_pairs_max() { return kStepPendingPairs; }

@@ -159,7 +159,13 @@ typedef enum {
     EKF_FORM_COLUMN_PANEL = 1u << 10,
     /* test hook: the panel plans ONE landmark per flush period, so panel rows and matrix gathers are mixed in one launch. */
     EKF_FORM_COLUMN_PANEL_ONE_SLOT = 1u << 11,
-    EKF_FORMS_DEFAULT = ((1u << 9) - 1) | (1u << 10)
+    /* pools' delayed data_association() (ekf_batch_run_unknown in delayed mode): a launch in front of every step guesses each
+     * reading's winner (the landmark nearest to where the reading lands) and rebuilds "stored covariance minus the pairs of
+     * earlier steps" for the guessed landmarks' rows / columns ONCE per step; the step kernel continues from it where its own
+     * decision agrees and rebuilds from scratch where it does not -- the pending store is read once per step instead of once
+     * per reading.  Same operations in the same order: bit-identical.  Off: every reading rebuilds. */
+    EKF_FORM_STEP_SPECULATE = 1u << 12,
+    EKF_FORMS_DEFAULT = ((1u << 9) - 1) | (1u << 10) | (1u << 12)
 } ekf_form;
 ekf_status ekf_set_forms(ekf_handle h, unsigned forms);
 ekf_status ekf_get_forms(ekf_handle h, unsigned* forms);

@@ -525,3 +525,41 @@ def test_delayed_data_association_with_a_step_nobody_reads(hip, k, silent):
         assert np.abs(snap[0][2][b] - snap[1][2][b]).max() < 1e-9, f"filter {b}"
     for i, b in enumerate((0, B - 1)):
         assert_parity(snap[1][2][b], snap[1][3][i], snap[0][2][b], snap[0][3][i], FP64_TOL, f"delayed vs eager, filter {b}")
+
+
+@pytest.mark.parametrize("k,surveyed_share,symmetric", [(32, 1.0, False), (64, 0.6, False), (24, 1.0, False), (32, 1.0, True)])
+def test_speculative_old_part_is_bit_identical(hip, k, surveyed_share, symmetric):
+    """EKF_FORM_STEP_SPECULATE (pools' delayed data_association()): a launch in front of every step guesses each reading's
+    winner and rebuilds "stored covariance minus the pairs of earlier steps" for the guessed landmarks once per step
+    (k_pool_step_spec); the step kernel continues from it where its decision agrees (ekf_slam.cpp:300-309 decides, :331-390
+    corrects) and rebuilds from scratch where it does not -- new landmarks, readings between the gates, filters still
+    discovering their map.  Same operations in the same order: decisions, known counts, states and covariances must be
+    BIT-identical to the run with the form off; ragged reading counts, filters that sit steps out, a run boundary."""
+    n, B, T = 150, 10, 12
+    cfg = synth.SimConfig(n=n, steps=T, filters=B, seed=6161, half_extent=5.0, min_spacing=0.3, max_visible_dis=1.4, vmax=8,
+                          v_cmd=1.0, w_cmd=0.6)
+    log = synth.make_unknown_log(cfg)
+    cnt = log.count.copy()
+    cnt[4, ::3] = 0
+    meas = log.meas_xy.copy()
+    meas[6, :, 0] += (0.2, -0.15)         # off-landmark readings: the guess (nearest landmark) and the decision may part
+    rng = np.random.default_rng(9)
+    init = (log.world[None] + rng.normal(0.0, 0.005, size=(B, n, 2))).reshape(B, 2 * n)
+    lm0 = np.full((2, B, 1), -1, dtype=np.int32)
+    known0 = np.where(np.arange(B) < surveyed_share * B, n, 0).astype(np.int32)
+    snap = []
+    for forms in (hip.FORMS_DEFAULT, hip.FORMS_DEFAULT & ~hip.FORM_STEP_SPECULATE):
+        bt = hip.BatchEKF(B, n)
+        bt.set_forms(forms)
+        bt.upload_known_log(np.zeros((2, B, 2)), lm0, np.zeros((2, B, 1, 2)), init)
+        bt.run_known()
+        bt.set_known_counts(known0)
+        bt.set_update_mode(k, symmetric_gather=symmetric)
+        bt.upload_unknown_log(log.twist, cnt, meas)
+        bt.run_unknown(0, 7); bt.run_unknown(7, T)
+        snap.append((bt.decisions().copy(), bt.known_counts().copy(), [bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)]))
+        bt.close()
+    assert np.array_equal(snap[0][0], snap[1][0]) and np.array_equal(snap[0][1], snap[1][1])
+    assert (snap[0][0] >= 0).sum() > 300
+    for b in range(B):
+        assert np.array_equal(snap[0][2][b], snap[1][2][b]) and np.array_equal(snap[0][3][b], snap[1][3][b]), f"filter {b}"
