@@ -458,9 +458,9 @@ ekf_status ekf_batch_run_unknown(ekf_batch_handle hb, int t_begin, int t_end, in
             EKFC(P.ensure_blk_cache());
             if (Nstep > 3 + 2 * kc_max) kc_max = (Nstep - 3) / 2;
             if (P.pend_count + 2 * jmax > P.pend_cap) EKFC(timed_flush());
-            // pairs of earlier steps pending: their part of what this step's gains need is rebuilt ONCE, for the landmarks
-            // the readings are guessed to match (EKF_FORM_STEP_SPECULATE; ekf_stepfused.hip, k_pool_step_spec)
-            const bool speculate = P.step_speculate && P.pend_count > 0;
+            // the part of what this step's gains need that does not depend on the step's own readings -- stored entries minus the
+            // pairs of earlier steps -- is rebuilt ONCE, for the landmarks the readings are guessed to match (EKF_FORM_STEP_SPECULATE; ekf_stepfused.hip, k_pool_step_spec)
+            const bool speculate = P.step_speculate != 0;
             if (speculate) {
                 EKFC(P.ensure_spec());
                 ekf::launch_pool_step_spec(P.pv, P.ulog_meas + (size_t)t * B * jmax * 2, P.ulog_count + (size_t)t * B, jmax,

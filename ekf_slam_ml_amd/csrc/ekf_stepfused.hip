@@ -485,7 +485,8 @@ __global__ __launch_bounds__(256) void k_pool_step_spec(PoolView pv, const doubl
     const int n = pv.n, ld = pv.ld, N = pv.N;
     const int J = count ? count[b] : jmax;
     int* wout = specw_all + (size_t)b * kCallV;
-    if (J <= 0 || p0 <= 0) {   // (uniform) nothing to prepare
+    if (J <= 0) {   // (uniform) nothing to prepare (p0 = 0 right behind a flush: the old part is the stored entries themselves --
+                    // still one gather of the column sectors per step instead of one per reading)
         if (blockIdx.x == 0 && tid < kCallV) wout[tid] = -1;
         return;
     }
@@ -663,7 +664,7 @@ void launch_pool_step_unknown_delayed(const PoolView& pv, const double* meas, co
                                       double* blocks, const double* pred, hipStream_t s, const double* spec, const int* specw) {
     hipLaunchKernelGGL(k_pool_step_unknown<true>, dim3(pv.B), dim3(kStepThreads), 0, s, pv, meas, count, jmax, min_active,
                        assoc_out, pend.U, pend.V, corr_counter, cnt_scratch, jmax, pend.count / 2, pend.cap, blocks, pred,
-                       pend.symmetric != 0, pend.count > 0 ? spec : nullptr, specw);
+                       pend.symmetric != 0, spec, specw);
 }
 
 int step_pending_pairs_max() { return kStepPendingPairs; }
