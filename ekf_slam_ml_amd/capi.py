@@ -50,8 +50,8 @@ SYMBOLS = [
 FORM_SMALL_MAP, FORM_CALL_FUSED, FORM_ACTIVE_PREFIX = 1 << 0, 1 << 2, 1 << 3   # (1 << 1: retired, ignored)
 FORM_STEP_FUSED, FORM_STEP_SPLIT_PASS, FORM_DELAYED_PAIR, FORM_ROW_PACKING = 1 << 4, 1 << 5, 1 << 6, 1 << 7
 FORM_STRIP_FLUSH, FORM_STRIP_FLUSH_ALWAYS = 1 << 8, 1 << 9
-FORM_COLUMN_PANEL, FORM_COLUMN_PANEL_ONE_SLOT, FORM_STEP_SPECULATE = 1 << 10, 1 << 11, 1 << 12
-FORMS_DEFAULT = ((1 << 9) - 1) | FORM_COLUMN_PANEL | FORM_STEP_SPECULATE
+FORM_COLUMN_PANEL, FORM_COLUMN_PANEL_ONE_SLOT, FORM_STEP_SPECULATE, FORM_CURRENT_COLUMNS = 1 << 10, 1 << 11, 1 << 12, 1 << 13
+FORMS_DEFAULT = ((1 << 9) - 1) | FORM_COLUMN_PANEL | FORM_STEP_SPECULATE | FORM_CURRENT_COLUMNS
 
 
 class EkfError(RuntimeError):

@@ -187,7 +187,7 @@ ekf_status ekf_batch_run_known(ekf_batch_handle hb, int t_begin, int t_end, int 
                     h++;
                 }
                 ekf::launch_panel_plan(P.pv, P.log_lm + (size_t)t_next * B * vmax, h, vmax, P.colp_slots, P.lmslot,
-                                       P.plan_list, P.stream);
+                                       P.plan_list, P.stream, P.curv[P.curv_sel], P.apred[P.curv_sel]);
                 pio.out = P.colp;
                 pio.lmslot = P.lmslot;
             }

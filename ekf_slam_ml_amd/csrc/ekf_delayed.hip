@@ -332,6 +332,12 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
             if (!SYM) uvc_append<4>(pend, b, pv.n, N, r, rc, z4, z4);
         }
         if (part == 0 && tid == 0) pv.rec[b].active = 0;
+        if (!SYM && pend.cur && part == 0 && tid == 0) {   // the kept rows / columns stay as they are (see Pending::cur)
+            const int nq = 1 + (pend.colp_rows - 3) / 2;
+            for (int q = 0; q < nq; q++) pend.curv_out[(size_t)b * nq + q] = pend.curv_in[(size_t)b * nq + q];
+            pend.apred_out[(size_t)b * 2] = pend.apred_in[(size_t)b * 2];           // (the deferred prediction map stays pending)
+            pend.apred_out[(size_t)b * 2 + 1] = pend.apred_in[(size_t)b * 2 + 1];
+        }
         return;
     }
     const bool two_corr = lm2 >= 0;
@@ -346,6 +352,18 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     const double* __restrict__ cp = (!SYM && pend.colp) ? pend.colp + (size_t)b * pend.colp_rows * ld : nullptr;
     const int slot1 = cp ? pend.lmslot[(size_t)b * pv.n + lm1] : -1;
     const int slot2 = cp ? pend.lmslot[(size_t)b * pv.n + lmB] : -1;
+    // current rows / columns (see Pending::cur): the pose group and each landmark's group start from what was kept after
+    // `st_*` pending vectors and fold only the vectors behind it; a group that was not kept starts from the stored entries
+    const int ncurv = cp ? 1 + (pend.colp_rows - 3) / 2 : 0;
+    double* __restrict__ cu = (cp && pend.cur) ? pend.cur + (size_t)b * (6 + 2 * (pend.colp_rows - 3)) * ld : nullptr;
+    int st_p = 0, st_a = 0, st_b = two_corr ? 0 : rc;   // (one correction: the second landmark's group is not needed at all)
+    bool kept_p = false, kept_a = false, kept_b = false;
+    if (cu) {
+        const int* cv = pend.curv_in + (size_t)b * ncurv;
+        if (cv[0] >= 0) { kept_p = true; st_p = cv[0]; }
+        if (slot1 >= 0 && cv[1 + slot1] >= 0) { kept_a = true; st_a = cv[1 + slot1]; }
+        if (two_corr && slot2 >= 0 && cv[1 + slot2] >= 0) { kept_b = true; st_b = cv[1 + slot2]; }
+    }
     // The lane's base entries Sigma(r, C[k]) and Sigma(C[k], r) are requested FIRST: they depend on nothing but the two
     // landmarks, and the workgroup's latency-bound prologue below (core block, the two corrections' terms on one lane,
     // three barriers: a tenth of a workgroup's life) then runs while they are in flight.
@@ -353,9 +371,18 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     const bool two = r + 1 < N;  // N is odd: the last lane owns one real index and one pad index
     double2_t p[7], g[7];        // Sigma(r, C[k]) and Sigma(C[k], r) for r and r + 1
     if (row_live) {
+        auto kept_of = [&](int k) { return k < 3 ? kept_p : k < 5 ? kept_a : kept_b; };
+        // row of cur that keeps the column (col = true) or the row (col = false) of core index k
+        auto cur_row = [&](int k, bool col) {
+            return k < 3 ? (col ? k : 3 + k) : k < 5 ? 6 + 4 * slot1 + (col ? 0 : 2) + (k - 3) : 6 + 4 * slot2 + (col ? 0 : 2) + (k - 5);
+        };
 #pragma unroll
         for (int k = 0; k < 7; k++) {
             const int c = cidx(k);
+            if (!SYM && kept_of(k)) {   // (uniform) the row as it stood after st_* pending vectors
+                g[k] = *reinterpret_cast<const double2_t*>(cu + (size_t)cur_row(k, false) * ld + r);
+                continue;
+            }
             g[k] = *reinterpret_cast<const double2_t*>(Sg + (size_t)c * ld + r);
             if (SYM && r < 4 && k >= 3) {   // Sigma(c, 1), Sigma(c, 2) from the rows 1, 2 (see Pending::symmetric == 2)
                 if (r == 0) g[k].y = Sg[(size_t)1 * ld + c];
@@ -369,24 +396,33 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
                 // panel on: every column that has a panel row is ONE coalesced 16-byte load (r, r + 1 are neighbours in the
                 // row); a landmark the plan did not hold is gathered from the matrix (its columns are current there)
 #pragma unroll
-                for (int k = 0; k < 3; k++) p[k] = *reinterpret_cast<const double2_t*>(cp + (size_t)k * ld + r);
-                if (slot1 >= 0) {
+                for (int k = 0; k < 3; k++)
+                    p[k] = *reinterpret_cast<const double2_t*>((kept_p ? cu + (size_t)cur_row(k, true) * ld : cp + (size_t)k * ld) + r);
+                if (kept_a) {
+                    p[3] = *reinterpret_cast<const double2_t*>(cu + (size_t)cur_row(3, true) * ld + r);
+                    p[4] = *reinterpret_cast<const double2_t*>(cu + (size_t)cur_row(4, true) * ld + r);
+                } else if (slot1 >= 0) {
                     p[3] = *reinterpret_cast<const double2_t*>(cp + (size_t)(3 + 2 * slot1) * ld + r);
                     p[4] = *reinterpret_cast<const double2_t*>(cp + (size_t)(4 + 2 * slot1) * ld + r);
                 } else {
                     const D2u b0 = *reinterpret_cast<const D2u*>(rw0 + cidx(3)), b1 = *reinterpret_cast<const D2u*>(rw1 + cidx(3));
                     p[3].x = b0.x; p[4].x = b0.y; p[3].y = b1.x; p[4].y = b1.y;
                 }
-                if (slot2 >= 0) {
+                if (kept_b) {
+                    p[5] = *reinterpret_cast<const double2_t*>(cu + (size_t)cur_row(5, true) * ld + r);
+                    p[6] = *reinterpret_cast<const double2_t*>(cu + (size_t)cur_row(6, true) * ld + r);
+                } else if (slot2 >= 0) {
                     p[5] = *reinterpret_cast<const double2_t*>(cp + (size_t)(3 + 2 * slot2) * ld + r);
                     p[6] = *reinterpret_cast<const double2_t*>(cp + (size_t)(4 + 2 * slot2) * ld + r);
                 } else {
                     const D2u c0 = *reinterpret_cast<const D2u*>(rw0 + cidx(5)), c1 = *reinterpret_cast<const D2u*>(rw1 + cidx(5));
                     p[5].x = c0.x; p[6].x = c0.y; p[5].y = c1.x; p[6].y = c1.y;
                 }
-                if (r < 4) {   // Sigma(c, 1), Sigma(c, 2) for the landmark rows c: the matrix's columns 1, 2 live in the panel
+                if (r < 4) {   // Sigma(c, 1), Sigma(c, 2) for the landmark rows c taken from the matrix: its columns 1, 2 live in
+                               // the panel (a kept row carries them itself: prediction() keeps its entries 1, 2 up)
 #pragma unroll
                     for (int k = 3; k < 7; k++) {
+                        if (kept_of(k)) continue;
                         if (r == 0) g[k].y = cp[(size_t)1 * ld + cidx(k)];
                         else g[k].x = cp[(size_t)2 * ld + cidx(k)];
                     }
@@ -402,6 +438,19 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
             if (!two) {
 #pragma unroll
                 for (int k = 0; k < 7; k++) p[k].y = 0.0;
+            }
+            if (kept_p) {
+                // the prediction(s) since these vectors were kept (Pending::apred_in): columns 1, 2 take column 0 * a, rows 1, 2
+                // take a * row 0 -- k_predict's expressions -- at the indices >= 3 (the pose block was mapped by k_predict)
+                const double as = pend.apred_in[(size_t)b * 2], bs = pend.apred_in[(size_t)b * 2 + 1];
+                if (r >= 4) {
+                    p[1].x = p[0].x * as + p[1].x; p[2].x = p[0].x * bs + p[2].x;
+                    g[1].x = as * g[0].x + g[1].x; g[2].x = bs * g[0].x + g[2].x;
+                }
+                if (r >= 2 && two) {
+                    p[1].y = p[0].y * as + p[1].y; p[2].y = p[0].y * bs + p[2].y;
+                    g[1].y = as * g[0].y + g[1].y; g[2].y = bs * g[0].y + g[2].y;
+                }
             }
         }
     }
@@ -516,6 +565,7 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
             if (j >= rc) return;   // (uniform)
 #pragma unroll
             for (int k = 0; k < 7; k++) {
+                if (j < (k < 3 ? st_p : k < 5 ? st_a : st_b)) continue;   // (uniform) this group was kept beyond vector j
                 const double v5a = sh_V7[k * kMaxPending + j], v5b = sh_V7[k * kMaxPending + j + 1];
                 const double u5a = sh_U7[k * kMaxPending + j], u5b = sh_U7[k * kMaxPending + j + 1];
                 if (!SYM) {
@@ -526,14 +576,27 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
                 g[k].y = __builtin_fma(-u5b, q.vb.y, __builtin_fma(-u5a, q.va.y, g[k].y));
             }
         };
-        if (rc > 0) {
+        const int j0 = min(st_p, min(st_a, st_b));   // the first pending vector any group still has to fold (even)
+        if (rc > j0) {
             Stage s0, s1, s2;
             s0.ua = s0.ub = s1.ua = s1.ub = s2.ua = s2.ub = zero2;
-            ld4(0, s0); ld4(2, s1);
-            for (int j = 0; j < rc; j += 6) {
+            ld4(j0, s0); ld4(j0 + 2, s1);
+            for (int j = j0; j < rc; j += 6) {
                 ld4(j + 4, s2); fold(j, s0);
                 ld4(j + 6, s0); fold(j + 2, s1);
                 ld4(j + 8, s1); fold(j + 4, s2);
+            }
+        }
+        if (!SYM && cu) {
+            // the rows / columns as they stand NOW (every pending vector folded, this launch's corrections not yet): kept for
+            // the next launch that meets the pose or these landmarks again (Pending::cur); curv_out says up to which vector
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const int sl = k < 5 ? slot1 : slot2;
+                if ((k >= 3 && sl < 0) || (k >= 5 && !two_corr)) continue;   // (uniform) no slot / no second landmark
+                const int rowc = k < 3 ? k : 6 + 4 * sl + ((k - 3) & 1), rowr = k < 3 ? 3 + k : rowc + 2;
+                *reinterpret_cast<double2_t*>(cu + (size_t)rowc * ld + r) = p[k];
+                *reinterpret_cast<double2_t*>(cu + (size_t)rowr * ld + r) = g[k];
             }
         }
         if (SYM) {
@@ -596,6 +659,16 @@ __global__ __launch_bounds__(256) void k_gain_delayed_pair(PoolView pv, CmdSrc s
     if (!SYM) {
         const double2_t kq[4] = {k1a, k1b, k2a, k2b}, gq[4] = {g1a, g1b, g2a, g2b};
         uvc_append<4>(pend, b, pv.n, N, r, rc, kq, gq);
+        if (cu && part == 0 && tid == 0) {   // (the filter's other workgroups read curv_in: the counts go to the other buffer)
+            int* co = pend.curv_out + (size_t)b * ncurv;
+            const int* ci = pend.curv_in + (size_t)b * ncurv;
+            for (int q = 0; q < ncurv; q++) co[q] = ci[q];
+            co[0] = rc;
+            if (slot1 >= 0) co[1 + slot1] = rc;
+            if (two_corr && slot2 >= 0) co[1 + slot2] = rc;
+            pend.apred_out[(size_t)b * 2] = 0.0;       // (applied by this launch, or nothing was kept to apply it to)
+            pend.apred_out[(size_t)b * 2 + 1] = 0.0;
+        }
     }
 }
 
@@ -1137,9 +1210,14 @@ bool sym_flush_applies(const PoolView& pv, const Pending& pend, const Rank2Tunin
 // a few dozen entries: microseconds.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_panel_plan(int B, int n, const int* __restrict__ lm_idx, int nsteps, int vmax,
-                                                   int slots, short* __restrict__ lmslot, int* __restrict__ plan_list) {
+                                                   int slots, short* __restrict__ lmslot, int* __restrict__ plan_list,
+                                                   int* __restrict__ curv_reset, double* __restrict__ apred_reset) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
+    if (curv_reset) {   // the flush behind this launch folds everything: no current row / column outlives it
+        for (int q = 0; q <= slots; q++) curv_reset[(size_t)b * (1 + slots) + q] = -1;
+        apred_reset[(size_t)b * 2] = 0.0; apred_reset[(size_t)b * 2 + 1] = 0.0;
+    }
     short* ls = lmslot + (size_t)b * n;
     int* pl = plan_list + (size_t)b * slots;
     for (int q = 0; q < slots; q++) {
@@ -1158,9 +1236,9 @@ __global__ __launch_bounds__(64) void k_panel_plan(int B, int n, const int* __re
 }
 
 void launch_panel_plan(const PoolView& pv, const int* lm_idx, int nsteps, int vmax, int slots, short* lmslot, int* plan_list,
-                       hipStream_t s) {
+                       hipStream_t s, int* curv_reset, double* apred_reset) {
     hipLaunchKernelGGL(k_panel_plan, dim3((pv.B + 63) / 64), dim3(64), 0, s, pv.B, pv.n, lm_idx, nsteps, vmax, slots, lmslot,
-                       plan_list);
+                       plan_list, curv_reset, apred_reset);
 }
 
 // matrix columns 1, 2 <- panel rows 1, 2 (the strided writes prediction() skipped while the panel was on).  grid (ceil(N / 256), B)

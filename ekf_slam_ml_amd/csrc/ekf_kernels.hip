@@ -191,6 +191,47 @@ __global__ __launch_bounds__(kPredictThreads) void k_predict(PoolView pv, const 
             uc[(size_t)2 * pend.cap + j] = double2_t{u2, v2};
         }
     }
+    // The CURRENT rows / columns a delayed run keeps for the pose indices and its planned landmarks (Pending::cur) are parts
+    // of Sigma as it stands now: At (.) At^T maps them like everything else -- the pose block here, the pose vectors' long
+    // part deferred to the next gain launch, a landmark's column / row at its entries 1, 2 here.
+    if (pend.cur) {
+        const int slots = (pend.colp_rows - 3) / 2;
+        double* cu = pend.cur + (size_t)b * (6 + 4 * slots) * ld;
+        const int* cv = pend.curv_in + (size_t)b * (1 + slots);
+        if (cv[0] >= 0) {
+            // (the pose vectors over the indices >= 3 -- Sigma(k, 1) = Sigma(k, 0) a10 + Sigma(k, 1), Sigma(1, k) = a10 Sigma(0, k)
+            // + Sigma(1, k), ... -- are left to the next gain launch, which applies the accumulated map to the values it
+            // loads: see Pending::apred_in)
+            if (threadIdx.x == 65) { pend.apred_in[(size_t)b * 2] += a10; pend.apred_in[(size_t)b * 2 + 1] += a20; }
+            if (threadIdx.x == 64) {   // the pose block of the kept vectors, from ITS values (rows of cur: Sigma(r, k))
+                double cc[3][3], T[3][3], Sn[3][3];
+                for (int r = 0; r < 3; r++)
+                    for (int k = 0; k < 3; k++) cc[r][k] = cu[(size_t)(3 + r) * ld + k];
+                for (int k = 0; k < 3; k++) {
+                    T[0][k] = cc[0][k];
+                    T[1][k] = a10 * cc[0][k] + cc[1][k];
+                    T[2][k] = a20 * cc[0][k] + cc[2][k];
+                }
+                for (int r = 0; r < 3; r++) {
+                    Sn[r][0] = T[r][0];
+                    Sn[r][1] = T[r][0] * a10 + T[r][1];
+                    Sn[r][2] = T[r][0] * a20 + T[r][2];
+                }
+                Sn[0][0] += pv.p.q_pose; Sn[1][1] += pv.p.q_pose; Sn[2][2] += pv.p.q_pose;
+                for (int r = 0; r < 3; r++)
+                    for (int k = 0; k < 3; k++) { cu[(size_t)(3 + r) * ld + k] = Sn[r][k]; cu[(size_t)k * ld + r] = Sn[r][k]; }
+            }
+        }
+        if ((int)threadIdx.x < 4 * slots) {
+            const int sl = threadIdx.x >> 2, q = threadIdx.x & 3;
+            if (cv[1 + sl] >= 0) {
+                double* vec = cu + (size_t)(6 + 4 * sl + q) * ld;
+                const double e0 = vec[0], e1 = vec[1], e2 = vec[2];
+                if (q < 2) { vec[1] = a10 * e0 + e1; vec[2] = a20 * e0 + e2; }   // a column: Sigma(1, c), Sigma(2, c)
+                else { vec[1] = e0 * a10 + e1; vec[2] = e0 * a20 + e2; }          // a row: Sigma(c, 1), Sigma(c, 2)
+            }
+        }
+    }
     if (threadIdx.x == 0) {
         st[0] = theta + u0;  // :99 -- theta is NOT wrapped after the prediction
         st[1] = px + u1;

@@ -67,6 +67,25 @@ struct Pending {
     // (PMC, profiles/r04: 7 % of the gain kernel's fetched bytes).  Written by the lane that owns index c when it appends
     // a pair, kept up (entries of the indices 1, 2) by prediction().
     double2_t* uvc;
+    // ... and CURRENT rows / columns, maintained lazily (nullptr = off).  Rebuilding Sigma(r, c) and Sigma(c, r) of a
+    // correction's indices as "stored minus ALL pending pairs" reads the whole pending store (count x 32 bytes per index);
+    // but a robot corrects the same few landmarks step after step, and the pose indices in every step.  cur[b][row][ld]
+    // keeps, for the pose indices and every planned landmark, the column and the row AS THEY STOOD after `curv` pending
+    // vectors; a gain launch starts from there, folds only the vectors appended since, and stores the result back.
+    // prediction() maps the kept vectors like the rest of Sigma (their entries 1, 2; the pose vectors wholesale).
+    // Rows: 0..2 columns 0, 1, 2; 3..5 rows 0, 1, 2; 6 + 4s + {0, 1} the columns of slot s, + {2, 3} its rows.
+    // curv [B][1 + slots]: [0] the pose vectors, [1 + s] slot s; -1 = not kept (start from the stored entries).  A launch
+    // reads curv_in and writes curv_out (the filter's other workgroups are still reading curv_in).
+    double* cur;
+    const int* curv_in;
+    int* curv_out;
+    // The kept POSE vectors (columns / rows 0..2 over the indices >= 3) are not rewritten by prediction(): it would cost ten
+    // vectors of traffic per step for a map Sigma(k, 1) += Sigma(k, 0) a10 (...) that the next gain launch can apply to the
+    // values it loads anyway.  k_predict adds its (a10, a20) to apred_in[b] (the map composes by addition: the two
+    // off-diagonal entries of At multiply into zero), the gain launch applies the sum on load and writes 0 to apred_out[b].
+    // The 3 x 3 pose block of the kept vectors and the landmarks' entries 1, 2 are mapped by k_predict itself, exactly.
+    double* apred_in;
+    double* apred_out;
 };
 // flush <-> panel: `in` (nullable) = the panel that has been on since the last flush (its rows 1, 2 ARE the matrix's
 // columns 1, 2); `out` (nullable) = the panel to write for the landmarks of `lmslot`
@@ -442,7 +461,8 @@ int launch_flush(const PoolView& pv, const Pending& pend, const Rank2Tuning& t, 
 // filter touch -- the log slots lm_idx[t][b][v] of `nsteps` steps from `lm_idx` on, in order, the first `slots` distinct
 // ones; plan_list [B][slots] remembers them so that the next plan can clear lmslot [B][n] again.
 void launch_panel_plan(const PoolView& pv, const int* lm_idx, int nsteps, int vmax, int slots, short* lmslot, int* plan_list,
-                       hipStream_t s);
+                       hipStream_t s, int* curv_reset = nullptr /* [B][1 + slots]: set to -1 (a flush follows) */,
+                       double* apred_reset = nullptr /* [B][2]: set to 0 */);
 // matrix columns 1, 2 <- panel rows 1, 2 (a run that ends on predictions with nothing pending)
 void launch_panel_repair(const PoolView& pv, const double* colp, int colp_rows, hipStream_t s);
 bool sym_flush_applies(const PoolView& pv, const Pending& pend, const Rank2Tuning& t);   // launch_flush would mirror

@@ -265,6 +265,7 @@ struct Pool {
         delayed_pair = (f & EKF_FORM_DELAYED_PAIR) ? 1 : 0;
         column_panel = (f & EKF_FORM_COLUMN_PANEL) ? ((f & EKF_FORM_COLUMN_PANEL_ONE_SLOT) ? 2 : 1) : 0;
         step_speculate = (f & EKF_FORM_STEP_SPECULATE) ? 1 : 0;
+        current_columns = (f & EKF_FORM_CURRENT_COLUMNS) ? 1 : 0;
         tuning.row_packing = (f & EKF_FORM_ROW_PACKING) ? 1 : 0;
         tuning.strip_flush = (f & EKF_FORM_STRIP_FLUSH_ALWAYS) ? 2 : (f & EKF_FORM_STRIP_FLUSH) ? 1 : 0;
         return EKF_OK;
@@ -277,7 +278,13 @@ struct Pool {
 
     ekf::Pending pending() const {
         ekf::Pending p{Uf, Vf, pend_cap, pend_count, pend_symmetric};
-        if (panel_active) { p.colp = colp; p.lmslot = lmslot; p.colp_rows = colp_rows(); p.uvc = uvc; }
+        if (panel_active) {
+            p.colp = colp; p.lmslot = lmslot; p.colp_rows = colp_rows(); p.uvc = uvc;
+            if (current_columns && cur) {
+                p.cur = cur; p.curv_in = curv[curv_sel]; p.curv_out = curv[curv_sel ^ 1];
+                p.apred_in = apred[curv_sel]; p.apred_out = apred[curv_sel ^ 1];
+            }
+        }
         return p;
     }
 
@@ -291,6 +298,12 @@ struct Pool {
     ekf::double2_t* uvc = nullptr;   // [B][3 + 2 slots][cap]: (U_j(c), V_j(c)) of the pending factors at the panel's indices
     int colp_slots = 0;
     int column_panel = 1;         // 0 off, 1 on, 2 on with a ONE-slot plan (test hook: the gather fallback beside the panel)
+    // ... current rows / columns of the pose indices and the planned landmarks (Pending::cur; EKF_FORM_CURRENT_COLUMNS)
+    double* cur = nullptr;        // [B][6 + 4 slots][ld]
+    int* curv[2] = {nullptr, nullptr};   // [B][1 + slots] each: a paired gain launch reads one and writes the other
+    double* apred[2] = {nullptr, nullptr};   // [B][2] each: the deferred prediction map of the kept pose vectors, same ping-pong
+    int curv_sel = 0;
+    int current_columns = 1;
     bool panel_valid = false, panel_active = false;
     int colp_rows() const { return 3 + 2 * colp_slots; }
     ekf_status free_panel() {
@@ -298,7 +311,12 @@ struct Pool {
         if (lmslot) HIPC(hipFree(lmslot));
         if (plan_list) HIPC(hipFree(plan_list));
         if (uvc) HIPC(hipFree(uvc));
-        colp = nullptr; lmslot = nullptr; plan_list = nullptr; uvc = nullptr; colp_slots = 0;
+        if (cur) HIPC(hipFree(cur));
+        for (int q = 0; q < 2; q++) if (curv[q]) HIPC(hipFree(curv[q]));
+        for (int q = 0; q < 2; q++) if (apred[q]) HIPC(hipFree(apred[q]));
+        apred[0] = apred[1] = nullptr;
+        colp = nullptr; lmslot = nullptr; plan_list = nullptr; uvc = nullptr; cur = nullptr; curv[0] = curv[1] = nullptr;
+        colp_slots = 0;
         panel_valid = panel_active = false;
         return EKF_OK;
     }
@@ -317,6 +335,16 @@ struct Pool {
         HIPC(hipMalloc((void**)&lmslot, nl * sizeof(short)));
         HIPC(hipMalloc((void**)&plan_list, nq * sizeof(int)));
         HIPC(hipMalloc((void**)&uvc, (size_t)pv.B * colp_rows() * pend_cap * sizeof(ekf::double2_t)));
+        const size_t nc = (size_t)pv.B * (6 + 4 * want) * pv.ld, nv = (size_t)pv.B * (1 + want);
+        HIPC(hipMalloc((void**)&cur, nc * sizeof(double)));
+        HIPC(hipMemsetAsync(cur, 0, nc * sizeof(double), stream));        // (pad entries of the rows stay 0)
+        for (int q = 0; q < 2; q++) {
+            HIPC(hipMalloc((void**)&curv[q], nv * sizeof(int)));
+            HIPC(hipMemsetAsync(curv[q], 0xFF, nv * sizeof(int), stream));   // -1: nothing kept
+            HIPC(hipMalloc((void**)&apred[q], (size_t)pv.B * 2 * sizeof(double)));
+            HIPC(hipMemsetAsync(apred[q], 0, (size_t)pv.B * 2 * sizeof(double), stream));
+        }
+        curv_sel = 0;
         HIPC(hipMemsetAsync(colp, 0, np * sizeof(double), stream));       // (pad entries of the rows stay 0)
         HIPC(hipMemsetAsync(lmslot, 0xFF, nl * sizeof(short), stream));   // -1: no landmark has a slot
         HIPC(hipMemsetAsync(plan_list, 0xFF, nq * sizeof(int), stream));
@@ -363,6 +391,7 @@ struct Pool {
         ekf::launch_gain_delayed_pair(pv, src, pending(), state_alt, stream);
         form_counts[2]++;
         if (panel_active) form_counts[7]++;
+        if (panel_active && current_columns && cur) curv_sel ^= 1;   // (the launch wrote the other count buffer)
         std::swap(pv.state, state_alt);
         pend_count += 4;
         return EKF_OK;
@@ -526,7 +555,7 @@ struct Pool {
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
                         phase_trace, terms2, scores2, blk_cache, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred,
-                        colp, lmslot, plan_list, uvc, spec, specw};
+                        colp, lmslot, plan_list, uvc, spec, specw, cur, curv[0], curv[1], apred[0], apred[1]};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();

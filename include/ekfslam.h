@@ -165,7 +165,14 @@ typedef enum {
      * decision agrees and rebuilds from scratch where it does not -- the pending store is read once per step instead of once
      * per reading.  Same operations in the same order: bit-identical.  Off: every reading rebuilds. */
     EKF_FORM_STEP_SPECULATE = 1u << 12,
-    EKF_FORMS_DEFAULT = ((1u << 9) - 1) | (1u << 10) | (1u << 12)
+    /* with the column panel (delayed known-association runs, paired gain launches): the rows and columns of Sigma at the pose
+     * indices and at every planned landmark are KEPT as they stand after each launch that rebuilt them, and the next launch
+     * that meets them folds only the pending vectors appended since -- a robot corrects the same few landmarks step after
+     * step, so a gain launch reads 4 factor vectors instead of all pending ones.  prediction() maps the kept vectors like
+     * the rest of Sigma.  The same quantities in another association of the sums: equal to the run without it to rounding
+     * (1e-10 in the tests, where the delayed mode itself sits 1e-10 from the eager run), not bit for bit.  Off: every launch rebuilds from the stored entries. */
+    EKF_FORM_CURRENT_COLUMNS = 1u << 13,
+    EKF_FORMS_DEFAULT = ((1u << 9) - 1) | (1u << 10) | (1u << 12) | (1u << 13)
 } ekf_form;
 ekf_status ekf_set_forms(ekf_handle h, unsigned forms);
 ekf_status ekf_get_forms(ekf_handle h, unsigned* forms);

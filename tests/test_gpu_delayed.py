@@ -390,7 +390,11 @@ def test_column_panel_is_bit_identical(hip, oracle, B, n, k, vmax, strip, blind_
         lm[-blind_tail:] = -1          # the run ends on predictions: nothing pending, matrix columns 1, 2 behind
     lm[7, 0] = -1                      # one filter sits a step out
     base = hip.FORMS_DEFAULT | (hip.FORM_STRIP_FLUSH_ALWAYS if strip else 0)
-    variants = {"panel": base, "one_slot": base | hip.FORM_COLUMN_PANEL_ONE_SLOT, "off": base & ~hip.FORM_COLUMN_PANEL}
+    nocur = base & ~hip.FORM_CURRENT_COLUMNS
+    # "current" / "current_one_slot": the panel WITH the kept current rows / columns (EKF_FORM_CURRENT_COLUMNS, the default):
+    # the same sums in another association -- compared at 1e-10
+    variants = {"panel": nocur, "one_slot": nocur | hip.FORM_COLUMN_PANEL_ONE_SLOT, "off": base & ~hip.FORM_COLUMN_PANEL,
+                "current": base, "current_one_slot": base | hip.FORM_COLUMN_PANEL_ONE_SLOT}
     outs, counts = {}, {}
     for name, forms in variants.items():
         for cuts in ((T,), (4, 5, 11, T)):          # one run; four consecutive runs (the panel is handed over)
@@ -406,15 +410,16 @@ def test_column_panel_is_bit_identical(hip, oracle, B, n, k, vmax, strip, blind_
             outs[name, cuts] = ([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)])
             bt.close()
     # a getter between two runs drops the panel: the next run starts without one (still the same numbers)
-    bt = hip.BatchEKF(B, n)
-    bt.set_forms(variants["panel"])
-    bt.set_update_mode(k)
-    bt.upload_known_log(log.twist, lm, log.z_xy, log.init_xy)
-    bt.run_known(0, 9)
-    mid = bt.state(0)
-    bt.run_known(9, T)
-    outs["panel", "getter"] = ([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)])
-    bt.close()
+    for name in ("panel", "current"):
+        bt = hip.BatchEKF(B, n)
+        bt.set_forms(variants[name])
+        bt.set_update_mode(k)
+        bt.upload_known_log(log.twist, lm, log.z_xy, log.init_xy)
+        bt.run_known(0, 9)
+        mid = bt.state(0)
+        bt.run_known(9, T)
+        outs[name, "getter"] = ([bt.state(b) for b in range(B)], [bt.cov(b) for b in range(B)])
+        bt.close()
     # (where the flushes fall changes the delayed mode's rounding -- its reconstruction and its flush contract their
     # multiply-adds -- so every variant is compared with the panel-less run over the SAME run boundaries)
     bt = hip.BatchEKF(B, n)
@@ -427,9 +432,14 @@ def test_column_panel_is_bit_identical(hip, oracle, B, n, k, vmax, strip, blind_
     for (name, cuts), (st, cv) in outs.items():
         ref = outs["off", cuts]
         for b in range(B):
-            assert np.array_equal(st[b], ref[0][b]) and np.array_equal(cv[b], ref[1][b]), f"{name} {cuts}, filter {b}"
+            if name.startswith("current"):
+                # (1e-10: on the n = 1000 shape the rebuilt form itself sits 1.3e-10 from the eager run, this form 1.2e-10)
+                assert np.abs(st[b] - ref[0][b]).max() < 1e-10, f"{name} {cuts}, filter {b}"
+                assert np.abs(cv[b] - ref[1][b]).max() / np.abs(ref[1][b]).max() < 1e-10, f"{name} {cuts}, filter {b}"
+            else:
+                assert np.array_equal(st[b], ref[0][b]) and np.array_equal(cv[b], ref[1][b]), f"{name} {cuts}, filter {b}"
     assert counts["off", (T,)]["gain_from_panel"] == 0
-    for name in ("panel", "one_slot"):
+    for name in ("panel", "one_slot", "current"):
         c1, c4 = counts[name, (T,)], counts[name, (4, 5, 11, T)]
         assert c4["gain_from_panel"] > 0, c4          # a closing flush hands the panel to the next run
         if c1["flush_plain"] + c1["flush_strip"] >= 2:  # (a single run has a panel from its first flush on)
@@ -440,6 +450,7 @@ def test_column_panel_is_bit_identical(hip, oracle, B, n, k, vmax, strip, blind_
     for t in range(T):
         o.prediction(*log.twist[t, b]); o.measurement_compact(log.init_xy[b], lm[t, b], log.z_xy[t, b])
     assert_parity(outs["panel", (T,)][0][b], outs["panel", (T,)][1][b], o.state, o.cov, FP64_TOL, "panel vs checker")
+    assert_parity(outs["current", (T,)][0][b], outs["current", (T,)][1][b], o.state, o.cov, FP64_TOL, "current columns vs checker")
     assert mid.shape == (3 + 2 * n,)
 
 
@@ -452,7 +463,7 @@ def test_column_panel_at_the_million_steps_configuration(hip):
     T = 1 + W + K
     log = synth.make_known_log(synth.config5(filters=B, steps=T, n=n))
     res = []
-    for forms in (hip.FORMS_DEFAULT, hip.FORMS_DEFAULT & ~hip.FORM_COLUMN_PANEL):
+    for forms in (hip.FORMS_DEFAULT & ~hip.FORM_CURRENT_COLUMNS, hip.FORMS_DEFAULT & ~hip.FORM_COLUMN_PANEL, hip.FORMS_DEFAULT):
         bt = hip.BatchEKF(B, n)
         bt.set_forms(forms)
         bt.set_update_mode(k)
@@ -469,3 +480,8 @@ def test_column_panel_at_the_million_steps_configuration(hip):
     for a, b in zip(res[0][3], res[1][3]):
         assert np.array_equal(a, b)
     assert np.array_equal(res[0][4], res[1][4])
+    # the default adds the kept current rows / columns: the same launches, results equal to rounding
+    assert res[2][0] == res[2][1] == K and res[2][2] == 2
+    for a, b in zip(res[2][3], res[1][3]):
+        assert np.abs(a - b).max() < 1e-10
+    assert np.abs(res[2][4] - res[1][4]).max() / np.abs(res[1][4]).max() < 1e-10
