@@ -558,6 +558,11 @@ def main():
             # average) and the 7 rows + 7 columns of the two landmarks are read once per PAIR; 4 rows of 8 N bytes are
             # appended per correction.  (One launch per landmark: 16 N (k - 1) + 112 N for these terms.)
             per_corr = (16.0 * Nf * Nf + 32.0 * Nf * kk) / kk + 0.5 * 16.0 * Nf * (kk - 2.0) + (0.5 * 14.0 + 4.0) * 8.0 * Nf
+            # With the kept current rows / columns (EKF_FORM_CURRENT_COLUMNS, the default) a paired gain launch no longer reads
+            # all pending factors: it reads and rewrites the 14 kept vectors of its 7 core indices, reads the 8 factor rows
+            # appended since the last launch, appends 8 rows and moves the state: 46 x 8 N bytes per PAIR in the steady state
+            # (a landmark met for the first time since the flush starts from the stored entries and all pending factors).
+            per_corr_kept = (16.0 * Nf * Nf + 32.0 * Nf * kk) / kk + 0.5 * 46.0 * 8.0 * Nf
             delayed = {"value": dcorr / dwall, "unit": "update steps/s", "corrections_per_flush": a.delayed_k,
                        "steps": Kd, "ms_per_step": dwall / Kd * 1e3, "flushes": sd["rank2_launches"],
                        "flush_avg_ms": sd["rank2_ms"] / max(sd["rank2_launches"], 1),
@@ -590,6 +595,10 @@ def main():
             fcn = bt.form_counts()
             delayed["flush_form"] = "k_flush_strip" if fcn["flush_strip"] else "k_flush"
             delayed["gain_launches_from_column_panel"] = fcn["gain_from_panel"]
+            if fcn["gain_from_panel"] and (bt.forms & capi.FORM_CURRENT_COLUMNS):
+                delayed["declared_bytes_per_correction"] = per_corr_kept
+                delayed["frac_of_8TBps"] = dcorr / world * per_corr_kept / dwall / 1e9 / HBM_PEAK_GBS
+                delayed["declared_bytes_rebuilt_form"] = per_corr   # (round 3's formula: every launch rebuilds from all pending factors)
             delayed["gain_launches_paired"] = fcn["gain_pairs"]
             if want_cpu:
                 from oracle import binding as ob  # checker only
