@@ -636,6 +636,25 @@ def main():
                                     "flush_form": "k_flush_sym" if bt.form_counts()["flush_mirrored"] else "full",
                                     "max_abs_state_diff_vs_eager": float(np.abs(gstate - rstate).max()),
                                     "max_rel_cov_diff_vs_eager": float(np.abs(gcov - rcov).max() / np.abs(rcov).max())}
+        # ... and the default form at the largest k the strip flush serves (40 corrections = 80 pending vectors): since the gain
+        # launch no longer grows with the pending count (kept current rows / columns), fewer, fuller flushes are what is left
+        # to gain.  Its own step count (whole flush periods); parity is the k = 32 leg's business.
+        k2 = 40
+        if a.delayed_k == 32 and T - (1 + W) >= k2 // 2:
+            K2 = (T - (1 + W)) // (k2 // 2) * (k2 // 2)
+            bt.reset()
+            bt.set_update_mode(k2)
+            bt.run_known(0, 1 + W)
+            fence()
+            t0 = time.perf_counter()
+            s2 = bt.run_known(1 + W, 1 + W + K2, time_kernels=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fence()
+            w2, c2, _ = shard.reduce_throughput(t1 - t0, float(s2["corrections"]), float(s2["filter_steps"]), device=red_dev)
+            if rank == 0:
+                delayed["k40"] = {"value": c2 / w2, "steps": K2, "flushes": s2["rank2_launches"],
+                                  "flush_avg_ms": s2["rank2_ms"] / max(s2["rank2_launches"], 1)}
         bt.set_update_mode(0)
 
     # Separately reported leg: the SAME steps with every measurement() call fused (ekf_callfused.hip) -- the gains and
