@@ -3,7 +3,8 @@
 // Every kernel serves a POOL of B independent filters (B = 1 for a single rigid2d::EKF_SLAM
 // object); blockIdx.z (or .y) selects the filter.  HBM layout per filter b:
 //   sigma  [N][ld]   fp64 row-major, ld = N rounded up to 16 doubles (rows start on 128-B lines,
-//                    so every lane moves aligned 16-B double2); pad columns stay 0
+//                    so every lane moves aligned 16-B double2) or, where that costs at most 1/32 of
+//                    a row, to 256 (rows on 2-KB boundaries: pick_ld, ekf_runtime.hpp); pad columns stay 0
 //   state  [ld]      [theta, x, y, m1x, m1y, ...]                  (ekf_slam.cpp:15-21,72-74)
 //   Kg     [ld][2]   Kalman gain rows (K(r,0), K(r,1))   (scratch between gain and rank-2 kernel)
 //   Gh     [2][ld]   rows of H*Sigma                      (pad entries 0)
