@@ -1003,7 +1003,7 @@ int rank2_packing(const PoolView& pv, const Rank2Tuning& t) {
     const int ld2n = pv.ld / 2;
     if (!t.row_packing) return 1;                             // EKF_FORM_ROW_PACKING off: the plain kernel
     if (ld2n < 64) return 1;                                  // a wavefront may straddle at most two sub-rows
-    if ((pv.N + 15) / 16 * 16 != pv.ld) return 1;             // a prefix view: columns beyond it must stay untouched
+    if (pick_ld(pv.N) != pv.ld) return 1;                     // a prefix view: columns beyond it must stay untouched
     auto util = [&](int P) { const long long w = (long long)P * ld2n; return (double)w / (double)((w + 255) / 256 * 256); };
     if (util(1) >= 0.93) return 1;
     if ((long long)pv.B * pv.N * ld2n < 256LL * 256 * 64) return 1;   // too little work for fat workgroups

@@ -4,7 +4,7 @@
 // object); blockIdx.z (or .y) selects the filter.  HBM layout per filter b:
 //   sigma  [N][ld]   fp64 row-major, ld = N rounded up to 16 doubles (rows start on 128-B lines,
 //                    so every lane moves aligned 16-B double2) or, where that costs at most 1/32 of
-//                    a row, to 256 (rows on 2-KB boundaries: pick_ld, ekf_runtime.hpp); pad columns stay 0
+//                    a row, to 256 (rows on 2-KB boundaries: pick_ld below); pad columns stay 0
 //   state  [ld]      [theta, x, y, m1x, m1y, ...]                  (ekf_slam.cpp:15-21,72-74)
 //   Kg     [ld][2]   Kalman gain rows (K(r,0), K(r,1))   (scratch between gain and rank-2 kernel)
 //   Gh     [2][ld]   rows of H*Sigma                      (pad entries 0)
@@ -427,6 +427,16 @@ __device__ __forceinline__ void wave_terms_s(int lane, const double* H, double r
     const int sq4 = lane & 3;
     const double si = (sq4 == 0 ? S11 : sq4 == 1 ? -S01 : sq4 == 2 ? -S10 : S00) / det;
     if (lane < 4) outSi[lane] = si;
+}
+
+// Leading dimension of Sigma, the factor vectors and the state: N rounded up to 16 doubles (rows on 128-byte lines), and
+// to 256 doubles -- rows on 2-KB boundaries -- where that costs at most 1/32 of a row (n = 1000: 2003 -> 2048, n = 5000:
+// 10003 -> 10240).  The strip-form flush reads a row as 2-KB pieces, one per workgroup: on a 2-KB boundary a piece is one
+// DRAM page visit instead of two halves (48.3 -> 47.0 ms at 64 pending vectors, 46.8 -> 43.9 at 2; k_rank2 40.09 -> 39.90:
+// profiles/r04/ld_alignment_ab.txt).
+inline int pick_ld(int N) {
+    const int wide = (N + 255) / 256 * 256;
+    return (wide - N) * 32 <= N ? wide : (N + 15) / 16 * 16;
 }
 
 // ---- host-side launchers (ekf_kernels.hip) ---------------------------------------------------

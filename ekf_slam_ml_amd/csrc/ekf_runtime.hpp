@@ -41,15 +41,6 @@ inline ekf_status fail(ekf_status st, const std::string& msg) {
     } while (0)
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-// Leading dimension of Sigma, the factor vectors and the state: N rounded up to 16 doubles (rows on 128-byte lines), and
-// to 256 doubles -- rows on 2-KB boundaries -- where that costs at most 1/32 of a row (n = 1000: 2003 -> 2048, n = 5000:
-// 10003 -> 10240).  The strip-form flush reads a row as 2-KB pieces, one per workgroup: on a 2-KB boundary a piece is one
-// DRAM page visit instead of two halves (48.3 -> 47.0 ms at 64 pending vectors, 46.8 -> 43.9 at 2; k_rank2 40.09 -> 39.90:
-// profiles/r04/ld_alignment_ab.txt).
-inline int pick_ld(int N) {
-    const int wide = round_up(N, 256);
-    return (wide - N) * 32 <= N ? wide : round_up(N, 16);
-}
 
 // pinned host buffer whose last async use is guarded by an event
 struct Staging {
@@ -517,7 +508,7 @@ struct Pool {
         pv.p = ekf::Params{p.sigma0_landmark, p.q_pose, p.r_meas, p.gate_new, p.gate_update, p.straight_eps};
         pv.n = n;
         pv.N = 3 + 2 * n;
-        pv.ld = pick_ld(pv.N);
+        pv.ld = ekf::pick_ld(pv.N);
         pv.B = B;
         pv.sigma_stride = (size_t)pv.N * pv.ld;
         EKFC(dalloc(&pv.sigma, (size_t)B * pv.sigma_stride));

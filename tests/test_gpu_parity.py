@@ -551,7 +551,7 @@ def test_device_normalize_angle_bit_exact(hip, oracle):
     assert np.array_equal(hip.normalize_angles(sub), np.array([ref.normalize_angle(float(x)) for x in sub]))
 
 
-@pytest.mark.parametrize("n,B", [(200, 64), (100, 200), (60, 540), (333, 24)])
+@pytest.mark.parametrize("n,B", [(200, 64), (100, 200), (60, 540), (333, 24), (376, 20)])   # (376: rows of 768 doubles, the 2-KB-boundary layout)
 def test_row_packed_rank2_is_bit_identical(hip, n, B):
     """Pools of narrow maps take the row-packed rank-2 kernel (P rows side by side fill the 256-lane strips; ragged last
     virtual row when N % P != 0, wavefronts straddling two sub-rows).  set_row_packing(False) (EKF_FORM_ROW_PACKING off) forces the plain kernel."""
