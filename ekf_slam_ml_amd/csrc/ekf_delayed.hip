@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void k_flush(double* __restrict__ sigma, const
     const int c2 = (p % strips) * 256 + threadIdx.x;
     const int row_begin = (p / strips) * rows_per_block;
     const int row_end = min(N, row_begin + rows_per_block);
-    if (c2 >= ld2n) return;
+    if (c2 >= (N + 1) / 2) return;   // (the columns behind N are padding: zero, and a product with V's zero padding keeps them so)
     const double* __restrict__ Ub = Uall + (size_t)b * cap * ld;
     const double2_t* __restrict__ Vb = reinterpret_cast<const double2_t*>(Vall + (size_t)b * cap * ld) + c2;
     double2_t* __restrict__ col = reinterpret_cast<double2_t*>(sigma + (size_t)b * sigma_stride) + c2;
@@ -928,7 +928,8 @@ __global__ __launch_bounds__(64 * kStripWaves, 1) void k_flush_strip(double* __r
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cbase = (p % strips) * kStripCols2 + lane;
-    const bool live0 = cbase < ld2n, live1 = cbase + 64 < ld2n;
+    const int nc2 = (N + 1) >> 1;   // double2 columns that hold the matrix: the padding behind them (up to 1/32 of a row) stays zero untouched
+    const bool live0 = cbase < nc2, live1 = cbase + 64 < nc2;
     const int row_begin = (p / strips) * rows_per_block;
     const int row_end = min(N, row_begin + rows_per_block);
     const double* __restrict__ Ub = Uall + (size_t)b * cap * ld;
@@ -1070,7 +1071,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_flush_sym(double* __restrict__ s
     const int r0 = ti * TR + 8 * wave;                             // the wave's first row
     const int cfirst = ti * TR + g * kSymCols;                     // the tile's first column
     const int c2 = (cfirst >> 1) + lane;                           // the lane's first double2 column (second: + 64)
-    const bool live0 = c2 < ld2n, live1 = c2 + 64 < ld2n;
+    const bool live0 = c2 < ((N + 1) >> 1), live1 = c2 + 64 < ((N + 1) >> 1);   // (padding columns: see k_flush_strip)
     const double* __restrict__ Ub = Uall + (size_t)b * cap * ld;
     const double2_t* __restrict__ Vb = reinterpret_cast<const double2_t*>(Vall + (size_t)b * cap * ld) + c2;
     double* __restrict__ Sg = sigma + (size_t)b * sigma_stride;
