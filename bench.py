@@ -456,7 +456,7 @@ def main():
 
     n = a.landmarks
     N = 3 + 2 * n
-    ld = (N + 255) // 256 * 256 if ((N + 255) // 256 * 256 - N) * 32 <= N else (N + 15) // 16 * 16   # (pick_ld, ekf_kernels.hpp)
+    ld = capi.leading_dimension(n)
     per_filter = N * ld * 8 + 6 * ld * 8 + 4 * n * 8
     free, total = torch.cuda.mem_get_info(local)
     B = a.filters if a.filters > 0 else 4096

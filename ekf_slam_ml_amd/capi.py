@@ -27,7 +27,7 @@ STATUS = {0: "EKF_OK", 1: "EKF_ERR_INVALID", 2: "EKF_ERR_NO_DEVICE", 3: "EKF_ERR
 
 # every symbol include/ekfslam.h declares (tests/test_host.py checks the .so exports them all)
 SYMBOLS = [
-    "ekf_last_error", "ekf_default_params", "ekf_device_count",
+    "ekf_last_error", "ekf_default_params", "ekf_leading_dimension", "ekf_device_count",
     "ekf_create", "ekf_destroy", "ekf_clone", "ekf_predict", "ekf_measure_known", "ekf_associate",
     "ekf_maha_scores", "ekf_get_pose", "ekf_get_landmarks", "ekf_dim", "ekf_get_state", "ekf_set_state",
     "ekf_get_cov", "ekf_set_cov", "ekf_get_init_flag", "ekf_set_init_flag", "ekf_sync", "ekf_set_tuning", "ekf_set_active_set", "ekf_batch_set_active_set", "ekf_batch_get_touched",
@@ -123,6 +123,8 @@ def load():
     h = C.c_void_p
     lib.ekf_last_error.restype = C.c_char_p
     lib.ekf_default_params.argtypes = [C.POINTER(Params)]
+    lib.ekf_leading_dimension.argtypes = [C.c_int]
+    lib.ekf_leading_dimension.restype = C.c_int
     lib.ekf_device_count.restype = C.c_int
     lib.ekf_default_sim_params.argtypes = [C.POINTER(SimParams)]
     lib.ekf_default_lidar_params.argtypes = [C.POINTER(LidarParams)]
@@ -209,6 +211,11 @@ def _check(st):
 
 def device_count():
     return load().ekf_device_count()
+
+
+def leading_dimension(n):
+    """doubles between two rows of a filter's covariance for a map of n landmarks (ekf_leading_dimension; needs no device)"""
+    return load().ekf_leading_dimension(int(n))
 
 
 def default_params():

@@ -10,6 +10,8 @@ extern "C" {
 
 const char* ekf_last_error(void) { return g_err.c_str(); }
 
+int ekf_leading_dimension(int n_landmarks) { return n_landmarks < 0 ? 0 : ekf::pick_ld(3 + 2 * n_landmarks); }
+
 void ekf_default_params(ekf_params* out) {
     if (!out) return;
     out->sigma0_landmark = 100.0;  // ekf_slam.cpp:32

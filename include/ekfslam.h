@@ -53,6 +53,10 @@ typedef struct ekf_batch_s* ekf_batch_handle; /* B independent filters (Monte-Ca
 
 const char* ekf_last_error(void);
 void ekf_default_params(ekf_params* out);
+/* Doubles between the starts of two rows of a filter's covariance (and the length of its state / factor vectors) for a map of
+ * n landmarks: N = 3 + 2 n rounded up to 16, or to 256 -- rows on 2-KB boundaries -- where that adds at most 1/32 of a row
+ * (n = 1000: 2048).  A filter takes 8 N ld bytes of device memory for its covariance.  Needs no device. */
+int ekf_leading_dimension(int n_landmarks);
 /* Number of visible HIP devices (0 if none); does not initialise a device context. */
 int ekf_device_count(void);
 

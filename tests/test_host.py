@@ -29,6 +29,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libekfslam_hip.so does not export {name}"
 
 
+def test_leading_dimension_rule():
+    """ekf_leading_dimension (no device needed): N = 3 + 2 n rounded up to 16 doubles, or to 256 -- rows on 2-KB boundaries --
+    where that adds at most 1/32 of a row; the values DESIGN.md section 2 and INTEGRATION.md quote."""
+    _built()
+    assert capi.leading_dimension(1000) == 2048 and capi.leading_dimension(5000) == 10240
+    assert capi.leading_dimension(200) == 416 and capi.leading_dimension(20) == 48 and capi.leading_dimension(0) == 16
+    for n in range(0, 6000, 7):
+        N, ld = 3 + 2 * n, capi.leading_dimension(n)
+        assert ld >= N and ld % 16 == 0
+        wide = (N + 255) // 256 * 256
+        assert ld == (wide if (wide - N) * 32 <= N else (N + 15) // 16 * 16)
+
+
 def test_no_cpu_fallback():
     """Without a HIP device the product must refuse to run (no silent CPU path)."""
     _built()
