@@ -73,7 +73,7 @@ __host__ __device__ inline void small_tile_origin(const DenseSplit& sp, int q, i
 template <bool BT, int NBUF, int WTM, int WTN>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const float* __restrict__ B,
                                           float* __restrict__ C, const float* __restrict__ Qadd, int ld, int row0,
-                                          int col0, float* smem) {
+                                          int col0, float* smem, int kdim) {
     constexpr int TM = 64 * WTM, TN = 64 * WTN;
     constexpr int SA = TM + 1;             // odd stride: conflict-free transposing stores and fragment reads
     constexpr int SB = BT ? TN + 1 : TN;   // a k-contiguous B operand is transposed like A; a row-major one is copied
@@ -146,7 +146,7 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, const flo
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    const int nk = ld / BK;
+    const int nk = (kdim + BK - 1) / BK;   // (the K range behind N is zero padding in both operands: 316 -> 313 K tiles at N = 10003)
     gload(0);
     lstore(0);
     __syncthreads();
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_big(const float* __restrict
     if (sp.n_big % 8 == 0) id = (id % 8) * (sp.n_big / 8) + id / 8;
     int tm, tn;
     big_tile_of(id, sp.tiles_m, sp.tiles_n, tm, tn);
-    gemm_tile<BT, 1, 4, 2>(A, B, C, Qadd, sp.ld, tm * 256, tn * 128, smem);
+    gemm_tile<BT, 1, 4, 2>(A, B, C, Qadd, sp.ld, tm * 256, tn * 128, smem, sp.n_rows);
 }
 
 template <bool BT>
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_f32_tail(const float* __restric
     small_tile_origin(sp, s >> 2, row0, col0);
     row0 += ((s >> 1) & 1) * 64;
     if (row0 >= sp.n_rows) return;   // (uniform) padding rows only: at N = 10003 half of the bottom strip's quarters
-    gemm_tile<BT, 1, 1, 1>(A, B, C, Qadd, sp.ld, row0, col0 + (s & 1) * 64, smem);
+    gemm_tile<BT, 1, 1, 1>(A, B, C, Qadd, sp.ld, row0, col0 + (s & 1) * 64, smem, sp.n_rows);
 }
 
 static size_t lds_bytes(int tm, int tn, bool bt) {
