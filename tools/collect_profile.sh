@@ -7,11 +7,12 @@ SRC=gpurun_out/prof_$TAG
 DST=profiles/$TAG
 mkdir -p $DST
 cp $SRC/summary.txt $DST/summary.txt
-cp $SRC/trace/*/*_kernel_stats.csv $DST/kernel_stats.csv
+# (gpurun merges every call's files into gpurun_out/: take the newest run's)
+cp "$(ls -t $SRC/trace/*/*_kernel_stats.csv | head -1)" $DST/kernel_stats.csv
 cp $SRC/bench_trace.json $DST/bench_under_trace.json
 # the PMC rows of the contract kernel only (the per-dispatch files hold every launch of every kernel)
 for k in fetch write; do
-  f=$(ls $SRC/pmc_$k/*/*_counter_collection.csv | head -1)
+  f=$(ls -t $SRC/pmc_$k/*/*_counter_collection.csv | head -1)
   { head -1 $f; grep "k_rank2<" $f; } > $DST/pmc_${k}_size.csv
 done
 cp $SRC/rank2_traffic.json profiles/rank2_traffic.json
