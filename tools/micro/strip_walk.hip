@@ -8,12 +8,11 @@
 #include <cstdio>
 #include <cstdlib>
 typedef double double2_t __attribute__((ext_vector_type(2)));
-constexpr int kWaves = 16;
 
 // map: 0 = a filter's workgroups on one XCD (the flush's decode); 1 = plain order (a filter's strips dealt round the XCDs);
 // rows_per_block / row_blocks: the strip cut into row blocks (workgroup = one row block of one strip); order: 0 = strips
 // fastest (row-major dispatch), 1 = row blocks fastest
-template <bool STRIP_MAJOR>
+template <bool STRIP_MAJOR, int kWaves = 16, int ROWS = 8, bool CONTIG = false>
 __global__ __launch_bounds__(64 * kWaves, 1) void k_walk(double* __restrict__ sigma, int N, int ld, int strips, int B, int map,
                                                          int row_blocks, int rows_per_block, int order) {
     extern __shared__ double2_t lds[];
@@ -41,25 +40,172 @@ __global__ __launch_bounds__(64 * kWaves, 1) void k_walk(double* __restrict__ si
     // double2 units
     const size_t rs = STRIP_MAJOR ? 128 : (size_t)(ld >> 1);
     double2_t* col = reinterpret_cast<double2_t*>(sigma + filter) + (STRIP_MAJOR ? (size_t)p * N * 128 : (size_t)p * 128) + lane;
-    const int ngroups = (row_end - row_begin + 7) >> 3;
-    for (int g = wave; g < ngroups; g += kWaves) {
-        const int r = row_begin + 8 * g;
-        double2_t a[8][2];
+    const int ngroups = (row_end - row_begin + ROWS - 1) / ROWS;
+    // CONTIG: wave w takes a contiguous run of groups instead of every kWaves-th one
+    const int per_wave = (ngroups + kWaves - 1) / kWaves;
+    const int g_begin = CONTIG ? wave * per_wave : wave, g_step = CONTIG ? 1 : kWaves;
+    const int g_end = CONTIG ? (g_begin + per_wave < ngroups ? g_begin + per_wave : ngroups) : ngroups;
+    for (int g = g_begin; g < g_end; g += g_step) {
+        const int r = row_begin + ROWS * g;
+        double2_t a[ROWS][2];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < ROWS; u++) {
             const size_t row = r + u < row_end ? r + u : row_end - 1;
             a[u][0] = __builtin_nontemporal_load(col + row * rs);
             a[u][1] = __builtin_nontemporal_load(col + row * rs + 64);
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) { a[u][0] += 1.0; a[u][1] += 1.0; }
+        for (int u = 0; u < ROWS; u++) { a[u][0] += 1.0; a[u][1] += 1.0; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < ROWS; u++) {
             if (r + u >= row_end) break;
             __builtin_nontemporal_store(a[u][0], col + (size_t)(r + u) * rs);
             __builtin_nontemporal_store(a[u][1], col + (size_t)(r + u) * rs + 64);
         }
     }
+}
+
+// the plain flush's shape: a workgroup of T threads = RB rows x (2 T) columns, dispatched strips-fastest, one group per wave
+template <int T, int RB>
+__global__ __launch_bounds__(T) void k_tile(double* __restrict__ sigma, int N, int ld, int strips, int row_blocks, int B) {
+    extern __shared__ double2_t lds[];
+    const int P = strips * row_blocks;
+    int b, pp;
+    const int full = (B / 8) * 8 * P;
+    if ((int)blockIdx.x < full) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b = (slot / P) * 8 + xcd;
+        pp = slot % P;
+    } else {
+        const int rest = blockIdx.x - full;
+        b = (B / 8) * 8 + rest / P;
+        pp = rest % P;
+    }
+    if (threadIdx.x == 0) lds[0] = double2_t{0.0, 0.0};
+    const int c2 = (pp % strips) * T + threadIdx.x, r0 = (pp / strips) * RB;
+    if (c2 >= (ld >> 1)) return;
+    double2_t* col = reinterpret_cast<double2_t*>(sigma + (size_t)b * N * ld) + c2;
+    const size_t rs = ld >> 1;
+    double2_t a[RB];
+#pragma unroll
+    for (int u = 0; u < RB; u++) a[u] = __builtin_nontemporal_load(col + (size_t)(r0 + u < N ? r0 + u : N - 1) * rs);
+#pragma unroll
+    for (int u = 0; u < RB; u++) a[u] += 1.0;
+#pragma unroll
+    for (int u = 0; u < RB; u++)
+        if (r0 + u < N) __builtin_nontemporal_store(a[u], col + (size_t)(r0 + u) * rs);
+}
+
+template <int T, int RB>
+static void tile_variant(double* s, int N, int ld, int B, size_t bytes, int lds, hipEvent_t e0, hipEvent_t e1) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile<T, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds > 0 ? lds : 16);
+    const int strips = (ld / 2 + T - 1) / T, row_blocks = (N + RB - 1) / RB;
+    const dim3 grid((unsigned)((long long)B * strips * row_blocks));
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_tile<T, RB>), grid, dim3(T), lds > 0 ? lds : 16, 0, s, N, ld, strips, row_blocks, B);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("tiles of %2d rows x %4d columns (%4d threads), LDS %3d KB per workgroup: %.2f ms, %.3f TB/s\n", RB, 2 * T, T, lds / 1024, best,
+           2.0 * bytes / (best * 1e-3) / 1e12);
+}
+
+// the strip walk shared by SHARE workgroups per strip, interleaved by rounds of 16 waves x 8 rows (workgroup j takes the rounds
+// j, j + SHARE, ...): SHARE x 8 workgroups sweep ONE window of a filter together; each stages `count` V rows of its strip
+// (2 KB each) into LDS first, like the flush (the first group's loads go out before the staging)
+template <int SHARE>
+__global__ __launch_bounds__(1024, 1) void k_shared(double* __restrict__ sigma, const double* __restrict__ vall, int N, int ld,
+                                                   int strips, int B, int count) {
+    extern __shared__ double2_t lds[];
+    const int P = strips * SHARE;
+    int b, pp;
+    const int full = (B / 8) * 8 * P;
+    if ((int)blockIdx.x < full) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b = (slot / P) * 8 + xcd;
+        pp = slot % P;
+    } else {
+        const int rest = blockIdx.x - full;
+        b = (B / 8) * 8 + rest / P;
+        pp = rest % P;
+    }
+    const int p = pp % strips, j = pp / strips;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t rs = ld >> 1;
+    double2_t* col = reinterpret_cast<double2_t*>(sigma + (size_t)b * N * ld) + (size_t)p * 128 + lane;
+    const int ngroups = (N + 7) >> 3;
+    int g = 16 * j + wave;
+    double2_t a[8][2];
+    auto load = [&](int gg) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const size_t row = 8 * gg + u < N ? 8 * gg + u : N - 1;
+            a[u][0] = __builtin_nontemporal_load(col + row * rs);
+            a[u][1] = __builtin_nontemporal_load(col + row * rs + 64);
+        }
+    };
+    if (g < ngroups) load(g);
+    const double2_t* vb = reinterpret_cast<const double2_t*>(vall + (size_t)b * 96 * ld) + (size_t)p * 128 + lane;
+    for (int q = wave; q < count; q += 16) {
+        lds[q * 128 + lane] = vb[(size_t)q * rs];
+        lds[q * 128 + 64 + lane] = vb[(size_t)q * rs + 64];
+    }
+    __syncthreads();
+    double2_t acc = lds[(wave % (count > 0 ? count : 1)) * 128 + lane];
+    while (g < ngroups) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a[u][0] += acc; a[u][1] += 1.0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (8 * g + u >= N) break;
+            __builtin_nontemporal_store(a[u][0], col + (size_t)(8 * g + u) * rs);
+            __builtin_nontemporal_store(a[u][1], col + (size_t)(8 * g + u) * rs + 64);
+        }
+        g += 16 * SHARE;
+        if (g < ngroups) load(g);
+    }
+}
+
+template <int SHARE>
+static void shared_variant(double* s, const double* v, int N, int ld, int strips, int B, size_t bytes, int count, hipEvent_t e0, hipEvent_t e1) {
+    const int lds = 160 * 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shared<SHARE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const dim3 grid((unsigned)((long long)B * strips * SHARE));
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_shared<SHARE>), grid, dim3(1024), lds, 0, s, v, N, ld, strips, B, count);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("strips shared by %d workgroups (rounds interleaved), %2d V rows staged: %.2f ms, %.3f TB/s\n", SHARE, count, best,
+           2.0 * bytes / (best * 1e-3) / 1e12);
+}
+
+template <int W, int R, bool C>
+static void variant(double* s, int N, int ld, int strips, int B, size_t bytes, int lds, hipEvent_t e0, hipEvent_t e1) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_walk<false, W, R, C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const dim3 grid((unsigned)((long long)B * strips));
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_walk<false, W, R, C>), grid, dim3(64 * W), lds, 0, s, N, ld, strips, B, 0, 1, (N + 7) & ~7, 0);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("whole strips, row-major, %2d waves x %2d rows per group, %s: %.2f ms, %.3f TB/s\n", W, R, C ? "contiguous runs " : "interleaved     ", best,
+           2.0 * bytes / (best * 1e-3) / 1e12);
 }
 
 int main(int argc, char** argv) {
@@ -72,6 +218,7 @@ int main(int argc, char** argv) {
     const int lds = 160 * 1024;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_walk<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    constexpr int kWaves = 16;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -94,6 +241,33 @@ int main(int argc, char** argv) {
                 if (rep == 2) printf("%-44s %s: %.2f ms, %.3f TB/s\n", c.name, mode ? "strip-major" : "row-major  ", ms, 2.0 * bytes / (ms * 1e-3) / 1e12);
             }
     }
+    double* v = nullptr;
+    if (hipMalloc(&v, (size_t)B * 96 * ld * sizeof(double)) != hipSuccess) { printf("hipMalloc of V failed\n"); return 1; }
+    hipMemset(v, 0, (size_t)B * 96 * ld * sizeof(double));
+    for (int count : {2, 64}) {
+        shared_variant<1>(s, v, N, ld, strips, B, bytes, count, e0, e1);
+        shared_variant<2>(s, v, N, ld, strips, B, bytes, count, e0, e1);
+        shared_variant<4>(s, v, N, ld, strips, B, bytes, count, e0, e1);
+    }
+    tile_variant<256, 16>(s, N, ld, B, bytes, 0, e0, e1);
+    tile_variant<256, 16>(s, N, ld, B, bytes, 40 * 1024, e0, e1);
+    tile_variant<256, 16>(s, N, ld, B, bytes, 80 * 1024, e0, e1);
+    tile_variant<256, 16>(s, N, ld, B, bytes, 160 * 1024, e0, e1);
+    tile_variant<128, 16>(s, N, ld, B, bytes, 0, e0, e1);
+    tile_variant<128, 32>(s, N, ld, B, bytes, 0, e0, e1);
+    tile_variant<1024, 16>(s, N, ld, B, bytes, 0, e0, e1);
+    tile_variant<1024, 16>(s, N, ld, B, bytes, 160 * 1024, e0, e1);
+    variant<16, 8, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<16, 8, true>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<16, 12, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<8, 16, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<8, 24, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<8, 8, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<4, 32, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<4, 8, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<4, 16, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<2, 8, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<4, 4, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
     if (hipGetLastError() != hipSuccess) { printf("HIP error\n"); return 1; }
     hipFree(s);
     return 0;
