@@ -96,6 +96,87 @@ __global__ __launch_bounds__(T) void k_tile(double* __restrict__ sigma, int N, i
         if (r0 + u < N) __builtin_nontemporal_store(a[u], col + (size_t)(r0 + u) * rs);
 }
 
+// the same tiles taken by RESIDENT workgroups: workgroup w of its XCD takes the entries w, w + G, w + 2 G, ... of the XCD's
+// row-major tile list (what the hardware dispatcher would have handed to short-lived workgroups, in software)
+template <int T, int RB, int MODE>
+__global__ __launch_bounds__(T) void k_tile_resident(double* __restrict__ sigma, int N, int ld, int strips, int row_blocks, int B) {
+    extern __shared__ double2_t lds[];
+    if (threadIdx.x == 0) lds[0] = double2_t{0.0, 0.0};
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, wgs = gridDim.x >> 3;
+    const int P = strips * row_blocks;
+    const long long list = (long long)((B - xcd + 7) / 8) * P;
+    const size_t rs = ld >> 1;
+    auto colof = [&](long long s) -> double2_t* {
+        const int b = (int)(s / P) * 8 + xcd, pp = (int)(s % P);
+        const int c2 = (pp % strips) * T + threadIdx.x, r0 = (pp / strips) * RB;
+        return reinterpret_cast<double2_t*>(sigma + (size_t)b * N * ld) + (c2 < (ld >> 1) ? c2 : 0) + (size_t)r0 * rs;
+    };
+    auto rowsof = [&](long long s) { const int pp = (int)(s % P); const int r0 = (pp / strips) * RB; return N - r0 < RB ? N - r0 : RB; };
+    if (MODE == 3) {
+        // two register sets: the next tile's loads go out BEFORE this tile's stores (s_waitcnt vmcnt counts loads and stores in
+        // one queue on gfx9: a load issued behind stores is not "there" before the stores are acknowledged)
+        double2_t a[RB], n[RB];
+        long long s = wg;
+        if (s >= list) return;
+        double2_t* col = colof(s);
+        int rows = rowsof(s);
+#pragma unroll
+        for (int u = 0; u < RB; u++) a[u] = __builtin_nontemporal_load(col + (size_t)(u < rows ? u : rows - 1) * rs);
+        for (;;) {
+            const long long s2 = s + wgs;
+            double2_t* col2 = s2 < list ? colof(s2) : col;
+            const int rows2 = s2 < list ? rowsof(s2) : rows;
+#pragma unroll
+            for (int u = 0; u < RB; u++) n[u] = __builtin_nontemporal_load(col2 + (size_t)(u < rows2 ? u : rows2 - 1) * rs);
+#pragma unroll
+            for (int u = 0; u < RB; u++) a[u] += 1.0;
+#pragma unroll
+            for (int u = 0; u < RB; u++)
+                if (u < rows) __builtin_nontemporal_store(a[u], col + (size_t)u * rs);
+            if (s2 >= list) break;
+#pragma unroll
+            for (int u = 0; u < RB; u++) a[u] = n[u];
+            s = s2; col = col2; rows = rows2;
+        }
+        return;
+    }
+    for (long long s = wg; s < list; s += wgs) {
+        double2_t* col = colof(s);
+        const int rows = rowsof(s);
+        double2_t a[RB];
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            const double2_t* src = col + (size_t)(u < rows ? u : rows - 1) * rs;
+            a[u] = MODE == 2 ? *src : __builtin_nontemporal_load(src);
+        }
+#pragma unroll
+        for (int u = 0; u < RB; u++) a[u] += 1.0;
+#pragma unroll
+        for (int u = 0; u < RB; u++)
+            if (u < rows) { if (MODE == 0) __builtin_nontemporal_store(a[u], col + (size_t)u * rs); else col[(size_t)u * rs] = a[u]; }
+    }
+}
+
+template <int T, int RB, int MODE>
+static void resident_variant(double* s, int N, int ld, int B, size_t bytes, int per_cu, hipEvent_t e0, hipEvent_t e1) {
+    const int lds = 160 * 1024 / per_cu - 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_resident<T, RB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int strips = (ld / 2 + T - 1) / T, row_blocks = (N + RB - 1) / RB;
+    const dim3 grid(256 * per_cu);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_tile_resident<T, RB, MODE>), grid, dim3(T), lds, 0, s, N, ld, strips, row_blocks, B);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("RESIDENT workgroups, %d per CU, tiles of %2d rows x %4d columns in the dispatcher's order, mode %d: %.2f ms, %.3f TB/s\n", per_cu, RB, 2 * T, MODE, best,
+           2.0 * bytes / (best * 1e-3) / 1e12);
+}
+
 template <int T, int RB>
 static void tile_variant(double* s, int N, int ld, int B, size_t bytes, int lds, hipEvent_t e0, hipEvent_t e1) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile<T, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds > 0 ? lds : 16);
@@ -249,6 +330,12 @@ int main(int argc, char** argv) {
         shared_variant<2>(s, v, N, ld, strips, B, bytes, count, e0, e1);
         shared_variant<4>(s, v, N, ld, strips, B, bytes, count, e0, e1);
     }
+    resident_variant<256, 16, 0>(s, N, ld, B, bytes, 1, e0, e1);
+    resident_variant<256, 16, 1>(s, N, ld, B, bytes, 1, e0, e1);
+    resident_variant<256, 16, 2>(s, N, ld, B, bytes, 1, e0, e1);
+    resident_variant<256, 16, 3>(s, N, ld, B, bytes, 1, e0, e1);
+    resident_variant<256, 16, 3>(s, N, ld, B, bytes, 2, e0, e1);
+    resident_variant<256, 16, 0>(s, N, ld, B, bytes, 2, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 0, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 40 * 1024, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 80 * 1024, e0, e1);
