@@ -12,7 +12,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // map: 0 = a filter's workgroups on one XCD (the flush's decode); 1 = plain order (a filter's strips dealt round the XCDs);
 // rows_per_block / row_blocks: the strip cut into row blocks (workgroup = one row block of one strip); order: 0 = strips
 // fastest (row-major dispatch), 1 = row blocks fastest
-template <bool STRIP_MAJOR, int kWaves = 16, int ROWS = 8, bool CONTIG = false>
+template <bool STRIP_MAJOR, int kWaves = 16, int ROWS = 8, bool CONTIG = false, bool DYN = false>
 __global__ __launch_bounds__(64 * kWaves, 1) void k_walk(double* __restrict__ sigma, int N, int ld, int strips, int B, int map,
                                                          int row_blocks, int rows_per_block, int order) {
     extern __shared__ double2_t lds[];
@@ -45,8 +45,15 @@ __global__ __launch_bounds__(64 * kWaves, 1) void k_walk(double* __restrict__ si
     const int per_wave = (ngroups + kWaves - 1) / kWaves;
     const int g_begin = CONTIG ? wave * per_wave : wave, g_step = CONTIG ? 1 : kWaves;
     const int g_end = CONTIG ? (g_begin + per_wave < ngroups ? g_begin + per_wave : ngroups) : ngroups;
-    for (int g = g_begin; g < g_end; g += g_step) {
+    unsigned* ctr = reinterpret_cast<unsigned*>(lds + 8);
+    if (DYN) {   // the waves take the strip's groups from a counter instead of every kWaves-th one
+        if (threadIdx.x == 0) *ctr = kWaves;
+        __syncthreads();
+    }
+    for (int g = g_begin; g < g_end;) {
         const int r = row_begin + ROWS * g;
+        int gnext = g + g_step;
+        if (DYN) { unsigned v = 0; if (lane == 0) v = atomicAdd(ctr, 1u); gnext = __builtin_amdgcn_readfirstlane(v); }
         double2_t a[ROWS][2];
 #pragma unroll
         for (int u = 0; u < ROWS; u++) {
@@ -62,6 +69,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void k_walk(double* __restrict__ si
             __builtin_nontemporal_store(a[u][0], col + (size_t)(r + u) * rs);
             __builtin_nontemporal_store(a[u][1], col + (size_t)(r + u) * rs + 64);
         }
+        g = gnext;
     }
 }
 
@@ -99,7 +107,8 @@ __global__ __launch_bounds__(T) void k_tile(double* __restrict__ sigma, int N, i
 // the same tiles taken by RESIDENT workgroups: workgroup w of its XCD takes the entries w, w + G, w + 2 G, ... of the XCD's
 // row-major tile list (what the hardware dispatcher would have handed to short-lived workgroups, in software)
 template <int T, int RB, int MODE>
-__global__ __launch_bounds__(T) void k_tile_resident(double* __restrict__ sigma, int N, int ld, int strips, int row_blocks, int B) {
+__global__ __launch_bounds__(T) void k_tile_resident(double* __restrict__ sigma, int N, int ld, int strips, int row_blocks, int B,
+                                                     unsigned* __restrict__ queue) {
     extern __shared__ double2_t lds[];
     if (threadIdx.x == 0) lds[0] = double2_t{0.0, 0.0};
     const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, wgs = gridDim.x >> 3;
@@ -140,6 +149,27 @@ __global__ __launch_bounds__(T) void k_tile_resident(double* __restrict__ sigma,
         }
         return;
     }
+    if (MODE == 4) {   // a queue per XCD: a workgroup takes the next entry when it is done with its last (what the dispatcher does)
+        __shared__ unsigned next;
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) next = atomicAdd(queue + xcd * 32, 1u);
+            __syncthreads();
+            const long long s = next;
+            if (s >= list) break;
+            double2_t* col = colof(s);
+            const int rows = rowsof(s);
+            double2_t a[RB];
+#pragma unroll
+            for (int u = 0; u < RB; u++) a[u] = __builtin_nontemporal_load(col + (size_t)(u < rows ? u : rows - 1) * rs);
+#pragma unroll
+            for (int u = 0; u < RB; u++) a[u] += 1.0;
+#pragma unroll
+            for (int u = 0; u < RB; u++)
+                if (u < rows) __builtin_nontemporal_store(a[u], col + (size_t)u * rs);
+        }
+        return;
+    }
     for (long long s = wg; s < list; s += wgs) {
         double2_t* col = colof(s);
         const int rows = rowsof(s);
@@ -159,14 +189,17 @@ __global__ __launch_bounds__(T) void k_tile_resident(double* __restrict__ sigma,
 
 template <int T, int RB, int MODE>
 static void resident_variant(double* s, int N, int ld, int B, size_t bytes, int per_cu, hipEvent_t e0, hipEvent_t e1) {
+    static unsigned* queue = nullptr;
+    if (!queue) hipMalloc(&queue, 8 * 32 * sizeof(unsigned));
     const int lds = 160 * 1024 / per_cu - 1024;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_resident<T, RB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int strips = (ld / 2 + T - 1) / T, row_blocks = (N + RB - 1) / RB;
     const dim3 grid(256 * per_cu);
     float best = 1e9f;
     for (int rep = 0; rep < 3; rep++) {
+        hipMemset(queue, 0, 8 * 32 * sizeof(unsigned));
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_tile_resident<T, RB, MODE>), grid, dim3(T), lds, 0, s, N, ld, strips, row_blocks, B);
+        hipLaunchKernelGGL((k_tile_resident<T, RB, MODE>), grid, dim3(T), lds, 0, s, N, ld, strips, row_blocks, B, queue);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -271,21 +304,21 @@ static void shared_variant(double* s, const double* v, int N, int ld, int strips
            2.0 * bytes / (best * 1e-3) / 1e12);
 }
 
-template <int W, int R, bool C>
+template <int W, int R, bool C, bool D = false>
 static void variant(double* s, int N, int ld, int strips, int B, size_t bytes, int lds, hipEvent_t e0, hipEvent_t e1) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_walk<false, W, R, C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_walk<false, W, R, C, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const dim3 grid((unsigned)((long long)B * strips));
     float best = 1e9f;
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_walk<false, W, R, C>), grid, dim3(64 * W), lds, 0, s, N, ld, strips, B, 0, 1, (N + 7) & ~7, 0);
+        hipLaunchKernelGGL((k_walk<false, W, R, C, D>), grid, dim3(64 * W), lds, 0, s, N, ld, strips, B, 0, 1, (N + 7) & ~7, 0);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         if (rep && ms < best) best = ms;
     }
-    printf("whole strips, row-major, %2d waves x %2d rows per group, %s: %.2f ms, %.3f TB/s\n", W, R, C ? "contiguous runs " : "interleaved     ", best,
+    printf("whole strips, row-major, %2d waves x %2d rows per group, %s: %.2f ms, %.3f TB/s\n", W, R, D ? "groups from a counter" : C ? "contiguous runs " : "interleaved     ", best,
            2.0 * bytes / (best * 1e-3) / 1e12);
 }
 
@@ -336,6 +369,8 @@ int main(int argc, char** argv) {
     resident_variant<256, 16, 3>(s, N, ld, B, bytes, 1, e0, e1);
     resident_variant<256, 16, 3>(s, N, ld, B, bytes, 2, e0, e1);
     resident_variant<256, 16, 0>(s, N, ld, B, bytes, 2, e0, e1);
+    resident_variant<256, 16, 4>(s, N, ld, B, bytes, 1, e0, e1);
+    resident_variant<256, 16, 4>(s, N, ld, B, bytes, 2, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 0, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 40 * 1024, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 80 * 1024, e0, e1);
@@ -345,6 +380,9 @@ int main(int argc, char** argv) {
     tile_variant<1024, 16>(s, N, ld, B, bytes, 0, e0, e1);
     tile_variant<1024, 16>(s, N, ld, B, bytes, 160 * 1024, e0, e1);
     variant<16, 8, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<16, 8, false, true>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<8, 8, false, true>(s, N, ld, strips, B, bytes, lds, e0, e1);
+    variant<16, 4, false, true>(s, N, ld, strips, B, bytes, lds, e0, e1);
     variant<16, 8, true>(s, N, ld, strips, B, bytes, lds, e0, e1);
     variant<16, 12, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
     variant<8, 16, false>(s, N, ld, strips, B, bytes, lds, e0, e1);
