@@ -40,7 +40,7 @@ SYMBOLS = [
     "ekf_circle_fit_scans", "ekf_normalize_angles",
     "ekf_default_lidar_params", "ekf_batch_simulate_unknown_log", "ekf_batch_download_unknown_log", "ekf_simulate_scans",
     "ekf_dense_create", "ekf_dense_destroy", "ekf_dense_set", "ekf_dense_propagate", "ekf_dense_get_sigma",
-    "ekf_dense_launch_info", "ekf_dense_tile_map", "ekf_batch_rank2_variant",
+    "ekf_dense_launch_info", "ekf_dense_tile_map", "ekf_batch_rank2_variant", "ekf_batch_rank2_resident",
     "ekf_set_profiling", "ekf_get_profile", "ekf_batch_set_known_counts",
     "ekf_set_forms", "ekf_get_forms", "ekf_batch_set_forms", "ekf_batch_get_forms", "ekf_batch_form_counts",
     "ekf_phase_trace", "ekf_test_raise_device_error",
@@ -51,7 +51,8 @@ FORM_SMALL_MAP, FORM_CALL_FUSED, FORM_ACTIVE_PREFIX = 1 << 0, 1 << 2, 1 << 3   #
 FORM_STEP_FUSED, FORM_STEP_SPLIT_PASS, FORM_DELAYED_PAIR, FORM_ROW_PACKING = 1 << 4, 1 << 5, 1 << 6, 1 << 7
 FORM_STRIP_FLUSH, FORM_STRIP_FLUSH_ALWAYS = 1 << 8, 1 << 9
 FORM_COLUMN_PANEL, FORM_COLUMN_PANEL_ONE_SLOT, FORM_STEP_SPECULATE, FORM_CURRENT_COLUMNS = 1 << 10, 1 << 11, 1 << 12, 1 << 13
-FORMS_DEFAULT = ((1 << 9) - 1) | FORM_COLUMN_PANEL | FORM_STEP_SPECULATE | FORM_CURRENT_COLUMNS
+FORM_TILE_QUEUE = 1 << 14
+FORMS_DEFAULT = ((1 << 9) - 1) | FORM_COLUMN_PANEL | FORM_STEP_SPECULATE | FORM_CURRENT_COLUMNS | FORM_TILE_QUEUE
 
 
 class EkfError(RuntimeError):
@@ -185,6 +186,7 @@ def load():
         "ekf_dense_launch_info": [h, _ip, _ip, _ip, _ip],
         "ekf_dense_tile_map": [h, _bp],
         "ekf_batch_rank2_variant": [h, _ip, _ip, _ip, _ip],
+        "ekf_batch_rank2_resident": [h, _ip],
         "ekf_batch_set_known_counts": [h, _ip],
         "ekf_set_profiling": [h, C.c_int],
         "ekf_set_forms": [h, C.c_uint],
@@ -620,7 +622,9 @@ class BatchEKF:
         v = [C.c_int() for _ in range(4)]
         _check(self._lib.ekf_batch_rank2_variant(self._h, *[C.byref(x) for x in v]))
         u, nt, tpb, rows = (x.value for x in v)
-        return f"ekf::k_rank2<{u},{'true' if nt else 'false'},{tpb}>", rows
+        res = C.c_int()
+        _check(self._lib.ekf_batch_rank2_resident(self._h, C.byref(res)))
+        return f"ekf::k_rank2{'_queue' if res.value else ''}<{u},{'true' if nt else 'false'},{tpb}>", rows
 
     def set_active_set(self, enable=True):
         """Stream only the rows of the touched set in the eager correction (exact; opt-in)."""

@@ -83,6 +83,13 @@ ekf_status ekf_batch_rank2_variant(ekf_batch_handle hb, int* group_rows, int* no
     return EKF_OK;
 }
 
+ekf_status ekf_batch_rank2_resident(ekf_batch_handle hb, int* resident) {
+    if (!hb || !resident) return fail(EKF_ERR_INVALID, "null argument");
+    EKFC(hb->pool.use());
+    *resident = ekf::rank2_resident(hb->pool.pv, hb->pool.tuning) ? 1 : 0;
+    return EKF_OK;
+}
+
 ekf_status ekf_batch_set_update_mode(ekf_batch_handle hb, int max_pending_corrections, int symmetric_gather) {
     if (!hb) return fail(EKF_ERR_INVALID, "null handle");
     return hb->pool.set_update_mode(max_pending_corrections, symmetric_gather);

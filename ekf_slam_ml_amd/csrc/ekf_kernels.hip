@@ -2,6 +2,8 @@
 // See ekf_kernels.hpp for the HBM layout.  Reference line numbers are rigid2d/src/ekf_slam.cpp.
 #include "ekf_kernels.hpp"
 
+#include <mutex>
+
 #include <limits.h>
 
 namespace ekf {
@@ -446,22 +448,21 @@ __device__ __forceinline__ void st2(double2_t* p, double2_t v) {
 // TPB: 256 lanes per strip, or 64 / 128 / 192 when the active row is shorter than that (a narrow map, or a
 // discovered prefix): the waves of a workgroup share nothing, so a narrower workgroup only sheds idle wavefronts.
 template <int U, bool NT, int TPB>
-__global__ __launch_bounds__(TPB) void k_rank2(double* __restrict__ sigma, const double* __restrict__ Kg_all,
-                                               const double* __restrict__ Gh_all, const CorrRec* __restrict__ rec,
-                                               double* __restrict__ state, int N_launch, int ld,
-                                               size_t sigma_stride, int rows_per_block) {
+__device__ __forceinline__ void rank2_tile(double* __restrict__ sigma, const double* __restrict__ Kg_all,
+                                           const double* __restrict__ Gh_all, const CorrRec* __restrict__ rec,
+                                           double* __restrict__ state, int N_launch, int ld, size_t sigma_stride,
+                                           int rows_per_block, int bx, int by, int b) {
     // N is the ACTIVE dimension: rows and columns >= N are exactly untouched by this correction (their K
     // and G entries are exact zeros), which data_association() exploits -- landmarks are appended in
     // discovery order, so everything beyond 3 + 2*known_count still holds its constructor value.
-    const int b = blockIdx.z;
     if (!rec[b].active) return;
     const int na = rec[b].n_active;  // per-filter discovered prefix (batched data association), 0 = none
     const int N = na > 0 ? min(na, N_launch) : N_launch;
     const int ld2n = ld >> 1;
     const int ld2a = (N + 1) >> 1;  // double2 columns that hold an active column
-    const int c2 = blockIdx.x * TPB + threadIdx.x;
+    const int c2 = bx * TPB + threadIdx.x;
     const double2_t* __restrict__ Kg = reinterpret_cast<const double2_t*>(Kg_all + (size_t)b * 2 * ld);
-    const int row_begin = blockIdx.y * rows_per_block;
+    const int row_begin = by * rows_per_block;
     const int row_end = min(N, row_begin + rows_per_block);
     if (row_begin >= N) return;
 
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(TPB) void k_rank2(double* __restrict__ sigma, const
     }
 
     // state = state + Ki*z_diff (:186); state(0) = normalize_angle(state(0)) (:187)
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
         const CorrRec rc = rec[b];
         double* st = state + (size_t)b * ld;
         for (int rr = row_begin + (int)threadIdx.x; rr < row_end; rr += TPB) {
@@ -547,6 +548,41 @@ __global__ __launch_bounds__(TPB) void k_rank2(double* __restrict__ sigma, const
             if (rr == 0) s = normalize_angle(s);
             st[rr] = s;
         }
+    }
+}
+
+template <int U, bool NT, int TPB>
+__global__ __launch_bounds__(TPB) void k_rank2(double* __restrict__ sigma, const double* __restrict__ Kg_all,
+                                               const double* __restrict__ Gh_all, const CorrRec* __restrict__ rec,
+                                               double* __restrict__ state, int N_launch, int ld,
+                                               size_t sigma_stride, int rows_per_block) {
+    rank2_tile<U, NT, TPB>(sigma, Kg_all, Gh_all, rec, state, N_launch, ld, sigma_stride, rows_per_block, blockIdx.x, blockIdx.y,
+                           blockIdx.z);
+}
+
+// The same tiles taken from ONE queue by resident workgroups (one per CU's worth of registers), for pools with many
+// more tiles than CUs.  The dispatcher deals workgroup i to XCD i % 8 -- a fixed eighth of the grid each -- and XCDs (and
+// CUs) do not stream at the same rate: tools/micro/strip_walk.hip moves the same bytes in 40.9 ms with short-lived
+// workgroups, 40.7 ms with a queue per XCD and 38.7 ms (6.94 TB/s) with one queue for the chip.  A workgroup asks for its
+// next tile (one atomicAdd, issued a tile ahead) when it is done with the last; tiles run column chunks fastest, then row
+// blocks, then filters, so the chip sweeps one filter at a time.  Same arithmetic per element: bit-identical.
+template <int U, bool NT, int TPB>
+__global__ __launch_bounds__(TPB) void k_rank2_queue(double* __restrict__ sigma, const double* __restrict__ Kg_all,
+                                                     const double* __restrict__ Gh_all, const CorrRec* __restrict__ rec,
+                                                     double* __restrict__ state, int N_launch, int ld, size_t sigma_stride,
+                                                     int rows_per_block, int chunks, int row_blocks, unsigned total,
+                                                     unsigned* __restrict__ queue) {
+    __shared__ unsigned sh_next[2];
+    unsigned ahead = 0;
+    if (threadIdx.x == 0) ahead = atomicAdd(queue, 1u);
+    for (int par = 0;; par ^= 1) {
+        if (threadIdx.x == 0) sh_next[par] = ahead;
+        __syncthreads();   // (one barrier per tile: the slot written now is read by everybody before it is written again two tiles on)
+        const unsigned s = __builtin_amdgcn_readfirstlane(sh_next[par]);   // (uniform: K and rec stay scalar loads in the tile body)
+        if (s >= total) break;
+        if (threadIdx.x == 0) ahead = atomicAdd(queue, 1u);   // the tile after this one: back long before it is needed
+        const int bx = s % chunks, by = (s / chunks) % row_blocks, b = s / ((unsigned)chunks * row_blocks);
+        rank2_tile<U, NT, TPB>(sigma, Kg_all, Gh_all, rec, state, N_launch, ld, sigma_stride, rows_per_block, bx, by, b);
     }
 }
 
@@ -948,10 +984,35 @@ void launch_gain(const PoolView& pv, const CmdSrc& src, hipStream_t s) {
     hipLaunchKernelGGL(k_gain, dim3((cover + 255) / 256, pv.B), dim3(256), 0, s, pv, src);
 }
 
+static int device_cus() {   // CUs of the current device (grid of the resident kernels)
+    constexpr int kMaxDev = 64;
+    static std::once_flag once[kMaxDev];
+    static int cus[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 0;
+    std::call_once(once[dev], [dev]() {
+        int v = 0;
+        cus[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess ? v : 0;
+    });
+    return cus[dev];
+}
+
 template <int U, int TPB>
-static void launch_rank2_ut(const PoolView& pv, int rows, bool nt, hipStream_t s) {
+static void launch_rank2_ut(const PoolView& pv, int rows, bool nt, hipStream_t s, bool resident) {
     const int ld2a = (pv.N + 1) / 2;
     dim3 grid((ld2a + TPB - 1) / TPB, (pv.N + rows - 1) / rows, pv.B);
+    // resident workgroups on one tile queue (rank2_resident: big pools only), the queue word zeroed in front
+    const long long total = (long long)grid.x * grid.y * grid.z;
+    const int cus = device_cus();
+    if (resident && hipMemsetAsync(pv.queue, 0, sizeof(unsigned), s) == hipSuccess) {
+        if (nt)
+            hipLaunchKernelGGL((k_rank2_queue<U, true, TPB>), dim3(cus), dim3(TPB), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
+                               pv.N, pv.ld, pv.sigma_stride, rows, (int)grid.x, (int)grid.y, (unsigned)total, pv.queue);
+        else
+            hipLaunchKernelGGL((k_rank2_queue<U, false, TPB>), dim3(cus), dim3(TPB), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
+                               pv.N, pv.ld, pv.sigma_stride, rows, (int)grid.x, (int)grid.y, (unsigned)total, pv.queue);
+        return;
+    }
     if (nt)
         hipLaunchKernelGGL((k_rank2<U, true, TPB>), grid, dim3(TPB), 0, s, pv.sigma, pv.Kg, pv.Gh, pv.rec, pv.state,
                            pv.N, pv.ld, pv.sigma_stride, rows);
@@ -961,12 +1022,12 @@ static void launch_rank2_ut(const PoolView& pv, int rows, bool nt, hipStream_t s
 }
 
 template <int U>
-static void launch_rank2_u(const PoolView& pv, int rows, bool nt, hipStream_t s) {
+static void launch_rank2_u(const PoolView& pv, int rows, bool nt, hipStream_t s, bool resident) {
     const int ld2a = (pv.N + 1) / 2;  // double2 columns of an active row
-    if (ld2a <= 64) launch_rank2_ut<U, 64>(pv, rows, nt, s);
-    else if (ld2a <= 128) launch_rank2_ut<U, 128>(pv, rows, nt, s);
-    else if (ld2a <= 192) launch_rank2_ut<U, 192>(pv, rows, nt, s);
-    else launch_rank2_ut<U, 256>(pv, rows, nt, s);
+    if (ld2a <= 64) launch_rank2_ut<U, 64>(pv, rows, nt, s, resident);
+    else if (ld2a <= 128) launch_rank2_ut<U, 128>(pv, rows, nt, s, resident);
+    else if (ld2a <= 192) launch_rank2_ut<U, 192>(pv, rows, nt, s, resident);
+    else launch_rank2_ut<U, 256>(pv, rows, nt, s, resident);
 }
 
 // which instantiation of k_rank2 (and how many rows per workgroup) a launch over this view takes
@@ -1012,6 +1073,17 @@ int rank2_packing(const PoolView& pv, const Rank2Tuning& t) {
     return 1;
 }
 
+// Whether a launch over this view runs as resident workgroups on one tile queue (k_rank2_queue): the 256-lane, 16-row-group
+// instantiation on pools with at least 16 tiles per CU
+bool rank2_resident(const PoolView& pv, const Rank2Tuning& t) {
+    int u, nti, tpb, rows;
+    rank2_variant(pv, t, &u, &nti, &tpb, &rows);
+    if (!t.tile_queue || !pv.queue || u != 16 || tpb != 256) return false;
+    const int cus = device_cus();
+    const long long total = (long long)(((pv.N + 1) / 2 + tpb - 1) / tpb) * ((pv.N + rows - 1) / rows) * pv.B;
+    return cus > 0 && total >= 16LL * cus && total < 0x7fffffffLL;
+}
+
 void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s, bool full_width) {
     int u, nti, tpb, rows;
     rank2_variant(pv, t, &u, &nti, &tpb, &rows);
@@ -1036,11 +1108,12 @@ void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s, bool 
         }
         return;
     }
+    const bool resident = rank2_resident(pv, t);
     switch (u) {
-        case 2: launch_rank2_u<2>(pv, rows, nt, s); break;
-        case 4: launch_rank2_u<4>(pv, rows, nt, s); break;
-        case 16: launch_rank2_u<16>(pv, rows, nt, s); break;
-        default: launch_rank2_u<8>(pv, rows, nt, s); break;
+        case 2: launch_rank2_u<2>(pv, rows, nt, s, resident); break;
+        case 4: launch_rank2_u<4>(pv, rows, nt, s, resident); break;
+        case 16: launch_rank2_u<16>(pv, rows, nt, s, resident); break;
+        default: launch_rank2_u<8>(pv, rows, nt, s, resident); break;
     }
 }
 

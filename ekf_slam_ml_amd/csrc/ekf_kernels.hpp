@@ -169,6 +169,8 @@ struct PoolView {
     // -- an in-kernel hand-off that never arrives -- sets a bit here instead of continuing with stale operands; the host
     // runtime turns a non-zero word into EKF_ERR_HIP at its next entry or synchronisation point (Pool::check_device).
     unsigned* err;
+    // one word of device scratch: the tile queue of the resident streaming kernels (k_rank2_queue); nullptr = none
+    unsigned* queue;
 };
 enum : unsigned { kErrHandoffTimeout = 1u };
 __device__ __forceinline__ void report_device_error(const PoolView& pv, unsigned bit) {
@@ -446,6 +448,7 @@ struct Rank2Tuning {
     int group_rows;      // rows per load/store group U in {2,4,8}; other values: automatic
     int row_packing;     // 1: narrow full-width views may take the row-packed kernel (EKF_FORM_ROW_PACKING)
     int strip_flush;     // delayed mode: 0 never, 1 automatic, 2 always the strip-form flush (EKF_FORM_STRIP_FLUSH*)
+    int tile_queue;      // 1: big pools stream the rank-2 update as resident workgroups on one tile queue (EKF_FORM_TILE_QUEUE)
 };
 
 void launch_init(const PoolView& pv, hipStream_t s);
@@ -487,6 +490,7 @@ void launch_rank2(const PoolView& pv, const Rank2Tuning& t, hipStream_t s, bool 
 int rank2_packing(const PoolView& pv, const Rank2Tuning& t);
 // the k_rank2<U, NT, TPB> instantiation and rows per workgroup launch_rank2 takes for this view (report hook)
 void rank2_variant(const PoolView& pv, const Rank2Tuning& t, int* u, int* nontemporal, int* tpb, int* rows);
+bool rank2_resident(const PoolView& pv, const Rank2Tuning& t);   // the launch runs as k_rank2_queue (EKF_FORM_TILE_QUEUE)
 // Same update restricted to the rows of the touched set (exact: every other row has K = 0).
 // max_touched: host-side upper bound of touch_count over the pool (sizes the grid).
 void launch_rank2_active(const PoolView& pv, const Rank2Tuning& t, int max_touched, hipStream_t s);

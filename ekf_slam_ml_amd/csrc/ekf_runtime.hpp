@@ -93,7 +93,7 @@ struct Pool {
     int device = -1;
     hipStream_t stream = nullptr;
     ekf::PoolView pv{};
-    ekf::Rank2Tuning tuning{0, -1, 0, 1, 1};
+    ekf::Rank2Tuning tuning{0, -1, 0, 1, 1, 1};
     size_t dev_bytes = 0;
     int init_flag = 0;  // landmark_init_flag, ekf_slam.hpp:65
 
@@ -268,6 +268,7 @@ struct Pool {
         current_columns = (f & EKF_FORM_CURRENT_COLUMNS) ? 1 : 0;
         tuning.row_packing = (f & EKF_FORM_ROW_PACKING) ? 1 : 0;
         tuning.strip_flush = (f & EKF_FORM_STRIP_FLUSH_ALWAYS) ? 2 : (f & EKF_FORM_STRIP_FLUSH) ? 1 : 0;
+        tuning.tile_queue = (f & EKF_FORM_TILE_QUEUE) ? 1 : 0;
         return EKF_OK;
     }
     void set_tuning(int rows_per_block, int nontemporal, int group_rows) {
@@ -529,6 +530,7 @@ struct Pool {
         HIPC(hipHostMalloc((void**)&err_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
         *err_host = 0u;
         pv.err = err_host;   // (unified addressing: the mapped pointer is valid on the device)
+        HIPC(hipMalloc((void**)&pv.queue, 64));   // (the resident streaming kernels' tile queue: one word, zeroed per launch)
         return reset();
     }
 
@@ -555,7 +557,7 @@ struct Pool {
                         assoc_out_dev, sensor_dev, digest_dev, poses_dev, log_twist, log_lm, log_z, log_init,
                         Uf, Vf, state_alt, assoc_alt, terms, log_truth, ulog_twist, ulog_count, ulog_meas, ulog_assoc, ulog_truth, corr_counter,
                         phase_trace, terms2, scores2, blk_cache, cf_U, cf_V, cf_cnt, cf_state, call_in, cf_pred,
-                        colp, lmslot, plan_list, uvc, spec, specw, cur, curv[0], curv[1], apred[0], apred[1]};
+                        colp, lmslot, plan_list, uvc, spec, specw, cur, curv[0], curv[1], apred[0], apred[1], pv.queue};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         stage_in.release();

@@ -176,7 +176,11 @@ typedef enum {
      * the rest of Sigma.  The same quantities in another association of the sums: equal to the run without it to rounding
      * (1e-10 in the tests, where the delayed mode itself sits 1e-10 from the eager run), not bit for bit.  Off: every launch rebuilds from the stored entries. */
     EKF_FORM_CURRENT_COLUMNS = 1u << 13,
-    EKF_FORMS_DEFAULT = ((1u << 9) - 1) | (1u << 10) | (1u << 12) | (1u << 13)
+    /* pools with many more rank-2 tiles than CUs stream the eager correction as RESIDENT workgroups that take their tiles from
+     * one queue (an atomicAdd per tile) instead of a grid of short-lived ones: the dispatcher deals a fixed eighth of a grid to
+     * each XCD, and XCDs / CUs do not stream at the same rate (tools/micro/strip_walk.hip).  Speed only: same arithmetic. */
+    EKF_FORM_TILE_QUEUE = 1u << 14,
+    EKF_FORMS_DEFAULT = ((1u << 9) - 1) | (1u << 10) | (1u << 12) | (1u << 13) | (1u << 14)
 } ekf_form;
 ekf_status ekf_set_forms(ekf_handle h, unsigned forms);
 ekf_status ekf_get_forms(ekf_handle h, unsigned* forms);
@@ -301,6 +305,8 @@ ekf_status ekf_batch_set_tuning(ekf_batch_handle hb, int rows_per_block, int non
  * full-width eager correction of this pool launches (bench.py ties its PMC traffic record to this name). */
 ekf_status ekf_batch_rank2_variant(ekf_batch_handle hb, int* group_rows, int* nontemporal, int* threads,
                                    int* rows_per_block);
+/* ... and whether that launch runs as resident workgroups on one tile queue (ekf::k_rank2_queue<...>, EKF_FORM_TILE_QUEUE). */
+ekf_status ekf_batch_rank2_resident(ekf_batch_handle hb, int* resident);
 ekf_status ekf_set_tuning(ekf_handle h, int rows_per_block, int nontemporal, int group_rows);
 
 /* ---- on-device Monte-Carlo inputs and consistency statistics --------

@@ -665,3 +665,31 @@ def test_degenerate_geometry_on_the_streaming_paths(hip, oracle, n, call_fused):
     assert np.array_equal(np.isnan(f.state), np.isnan(o.state))
     assert np.array_equal(np.isnan(f.cov), np.isnan(o.cov))
     f.close()
+
+
+@pytest.mark.parametrize("n,B", [(1000, 24), (500, 80)])
+def test_rank2_tile_queue_is_bit_identical(hip, n, B):
+    """Pools with many more rank-2 tiles than CUs stream the eager correction as resident workgroups that take their tiles
+    from one queue (k_rank2_queue, EKF_FORM_TILE_QUEUE: an atomicAdd per tile, the next one asked for a tile ahead) instead
+    of a grid of short-lived ones: the same arithmetic per element, so bit for bit the grid form's results -- and the form
+    is really taken (ekf_batch_rank2_resident) on these shapes and not on a small pool."""
+    cfg = synth.config5(filters=B, steps=5, n=n)
+    log = synth.make_known_log(cfg)
+    res = []
+    for queue in (True, False):
+        bt = hip.BatchEKF(B, n)
+        bt.set_call_fused(False)   # the per-landmark rank-2 stream
+        bt.set_forms((bt.forms | hip.FORM_TILE_QUEUE) if queue else (bt.forms & ~hip.FORM_TILE_QUEUE))
+        name, _ = bt.rank2_kernel()
+        assert ("k_rank2_queue<" in name) == queue, name
+        bt.upload_known_log(log.twist, log.lm_idx, log.z_xy, log.init_xy)
+        bt.run_known()
+        res.append(([bt.state(b) for b in (0, B // 2, B - 1)], [bt.cov(b) for b in (0, B // 2, B - 1)], bt.checksum()))
+        bt.close()
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert np.array_equal(a, b)
+    assert np.allclose(res[0][2], res[1][2], rtol=1e-12)   # (the pool checksum is summed in no fixed order)
+    small = hip.BatchEKF(2, 60)
+    small.set_call_fused(False)
+    assert "k_rank2_queue<" not in small.rank2_kernel()[0]
+    small.close()

@@ -13,7 +13,7 @@ cp $SRC/bench_trace.json $DST/bench_under_trace.json
 # the PMC rows of the contract kernel only (the per-dispatch files hold every launch of every kernel)
 for k in fetch write; do
   f=$(ls -t $SRC/pmc_$k/*/*_counter_collection.csv | head -1)
-  { head -1 $f; grep "k_rank2<" $f; } > $DST/pmc_${k}_size.csv
+  { head -1 $f; grep "k_rank2<\|k_rank2_queue<" $f; } > $DST/pmc_${k}_size.csv
 done
 cp $SRC/rank2_traffic.json profiles/rank2_traffic.json
 echo "collected into $DST; profiles/rank2_traffic.json refreshed"

@@ -149,6 +149,30 @@ __global__ __launch_bounds__(T) void k_tile_resident(double* __restrict__ sigma,
         }
         return;
     }
+    if (MODE == 5) {   // ONE queue for the whole chip (the dispatcher itself deals workgroup i to XCD i % 8: a fixed eighth each)
+        __shared__ unsigned next5;
+        const long long all = (long long)B * P;
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) next5 = atomicAdd(queue, 1u);
+            __syncthreads();
+            const long long s5 = next5;
+            if (s5 >= all) break;
+            const int b = (int)(s5 / P), pp = (int)(s5 % P);
+            const int c2 = (pp % strips) * T + threadIdx.x, r0 = (pp / strips) * RB;
+            double2_t* col = reinterpret_cast<double2_t*>(sigma + (size_t)b * N * ld) + (c2 < (ld >> 1) ? c2 : 0) + (size_t)r0 * rs;
+            const int rows = N - r0 < RB ? N - r0 : RB;
+            double2_t a[RB];
+#pragma unroll
+            for (int u = 0; u < RB; u++) a[u] = __builtin_nontemporal_load(col + (size_t)(u < rows ? u : rows - 1) * rs);
+#pragma unroll
+            for (int u = 0; u < RB; u++) a[u] += 1.0;
+#pragma unroll
+            for (int u = 0; u < RB; u++)
+                if (u < rows) __builtin_nontemporal_store(a[u], col + (size_t)u * rs);
+        }
+        return;
+    }
     if (MODE == 4) {   // a queue per XCD: a workgroup takes the next entry when it is done with its last (what the dispatcher does)
         __shared__ unsigned next;
         for (;;) {
@@ -371,6 +395,8 @@ int main(int argc, char** argv) {
     resident_variant<256, 16, 0>(s, N, ld, B, bytes, 2, e0, e1);
     resident_variant<256, 16, 4>(s, N, ld, B, bytes, 1, e0, e1);
     resident_variant<256, 16, 4>(s, N, ld, B, bytes, 2, e0, e1);
+    resident_variant<256, 16, 5>(s, N, ld, B, bytes, 1, e0, e1);
+    resident_variant<256, 16, 5>(s, N, ld, B, bytes, 2, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 0, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 40 * 1024, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 80 * 1024, e0, e1);
