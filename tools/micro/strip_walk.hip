@@ -396,6 +396,9 @@ int main(int argc, char** argv) {
     resident_variant<256, 16, 4>(s, N, ld, B, bytes, 1, e0, e1);
     resident_variant<256, 16, 4>(s, N, ld, B, bytes, 2, e0, e1);
     resident_variant<256, 16, 5>(s, N, ld, B, bytes, 1, e0, e1);
+    resident_variant<256, 32, 5>(s, N, ld, B, bytes, 1, e0, e1);
+    resident_variant<256, 8, 5>(s, N, ld, B, bytes, 1, e0, e1);
+    resident_variant<128, 32, 5>(s, N, ld, B, bytes, 1, e0, e1);
     resident_variant<256, 16, 5>(s, N, ld, B, bytes, 2, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 0, e0, e1);
     tile_variant<256, 16>(s, N, ld, B, bytes, 40 * 1024, e0, e1);
